@@ -1,0 +1,191 @@
+"""Oracle vs the known answers held by the reference's own tests
+(/root/reference/test_image_processing.py, "t.py"), restated under the signatures of the
+image_processing.py in the tree (SURVEY.md section 4 lists the API drift).  CPU only."""
+import numpy as np
+import pytest
+
+from oracle import cref, stages as S
+
+
+def test_persistent_simple():                       # t.py:333-342
+    m1 = np.array([[True, False], [True, True]])
+    m2 = np.array([[True, True], [False, True]])
+    p = S.compute_persistent_mask([m1, m2], 2)
+    assert p.dtype == bool and np.array_equal(p, [[True, False], [False, True]])
+
+
+@pytest.mark.parametrize("middle", [np.zeros((2, 2), bool), None])   # t.py:345-355 (+ the None form)
+def test_persistent_reset(middle):
+    m1 = np.array([[True, True], [False, True]])
+    m3 = np.array([[True, True], [True, False]])
+    assert not S.compute_persistent_mask([m1, middle, m3], 2).any()
+
+
+def test_filter_consecutive():                      # t.py:358-371, 375-384
+    masks = [np.array([[True, False], [True, True]]), np.array([[True, True], [False, True]])]
+    pers = np.array([[True, False], [False, True]])
+    f, c = S.filter_consecutive_pixels(masks, pers)
+    assert c == [1, 1] and f[0].shape == (2, 2)
+    f, c = S.filter_consecutive_pixels([None, np.array([[True]])], np.array([[False]]))
+    assert f[0] is None and np.isnan(c[0]) and c[1] == 1
+
+
+def test_final_count():                             # t.py:422-430, SURVEY App. B
+    masks = [np.array([[1, 1], [0, 1]], bool), np.zeros((2, 2), bool)]
+    out = S.get_final_count(masks, [10, np.nan])
+    assert out.tolist() == [13.0, 0.0]
+    out = S.get_final_count([masks[0], None], [10, np.nan])
+    assert out[0] == 13.0 and np.isnan(out[1])
+
+
+def test_static_mask():                             # t.py:461-473
+    frames = np.array([[[10, 200], [200, 10]], [[10, 200], [200, 10]], [[10, 50], [50, 10]]])
+    masks = np.array([f > 170 for f in frames])
+    out = S.compute_static_mask(frames, masks, 180, 50, 1)
+    assert np.array_equal(out, [[False, True], [True, False]])
+
+
+def test_static_suppression():                      # t.py:476-493
+    m1 = np.array([[True, False], [True, True]])
+    pers = np.array([[True, False], [False, False]])
+    stat = np.array([[False, True], [False, False]])
+    fm, counts = S.apply_static_suppression([m1, np.zeros((2, 2), bool), None], pers, stat)
+    exp = m1 & ~(pers | stat)
+    assert np.array_equal(fm[0], exp) and counts[0] == exp.sum()
+    assert not fm[1].any() and counts[1] == 0 and fm[2] is None and np.isnan(counts[2])
+
+
+def test_damaged_mask_simple():                     # t.py:559-571
+    frame = np.zeros((3, 3)); frame[1, 1] = 100
+    m, thr = S.get_damaged_pixel_mask(frame, np.zeros((3, 3)))
+    assert thr.shape == (3, 3) and np.all(thr == 30)
+    exp = np.zeros((3, 3), np.uint8); exp[1, 1] = 1
+    assert np.array_equal(m, exp)
+
+
+def test_damaged_mask_background_scaling():         # t.py:574-582
+    frame = np.zeros((2, 2)); frame[0, 0] = 200.0
+    bg = np.zeros((2, 2)); bg[0, 0] = 255.0
+    m, thr = S.get_damaged_pixel_mask(frame, bg)
+    assert thr[0, 0] == pytest.approx(255.0) and m[0, 0] == 0
+
+
+def test_cluster_filter_close_border():             # t.py:585-615 (pins App. A.4 conventions)
+    frame = np.arange(16).reshape(4, 4).astype(float)
+    m = np.zeros((4, 4), np.uint8)
+    m[0, 0] = m[0, 1] = 1
+    m[3, 2] = m[3, 3] = m[2, 3] = 1
+    cleaned, count, _, _ = S.filter_damaged_pixel_clusters(frame, m, 2, 2, 0.0)
+    assert count == 1 and cleaned.sum() == 2
+
+
+def test_remove_bright_regions():                   # t.py:618-646
+    bg = np.array([[50, 60], [70, 80]], float)
+    d = np.zeros((2, 2), bool); d[1, 1] = True
+    assert np.array_equal(S.remove_bright_regions(bg, 100, d, 2), d)
+    bg = np.array([[200, 200, 10], [200, 200, 10], [10, 10, 10]])
+    d = np.zeros((3, 3), bool)
+    assert np.array_equal(S.remove_bright_regions(bg, 100, d, 2), d)
+    d[0, 0] = True; d[2, 2] = True                   # touching / not touching the bright blob
+    exp = np.zeros((3, 3), bool); exp[2, 2] = True
+    assert np.array_equal(S.remove_bright_regions(bg, 100, d, 2), exp)
+
+
+def test_estimates():                               # t.py:649-703
+    frames = np.array([[[10, 10], [200, 200]], [[255, 255], [255, 255]]], np.float32)
+    masks = np.array([[[True, False], [False, False]], [[False, False], [False, False]]])
+    out = S.estimate_damaged_pixels_in_bright_areas(frames, masks, 100)
+    assert out[0] == pytest.approx(2.0) and np.isnan(out[1])
+    out = S.estimate_damaged_pixels_in_bright_areas([np.full((2, 2), 200.0)],
+                                                    [np.array([[False, True], [False, False]])], 100)
+    assert out.shape == (1,) and np.isnan(out[0])
+    frames = np.array([[[150, 200], [50, 80]], [[10, 20], [30, 40]]])
+    out = S.find_bright_area_estimates(frames, np.zeros((2, 2, 2), bool), 170)
+    assert out[0] == pytest.approx(0) and np.isnan(out[1])
+
+
+def test_flow_metric():                             # t.py:706-727
+    z = np.zeros((8, 8), np.uint8)
+    assert np.allclose(S.compute_optical_flow_metric([z, z.copy(), z.copy()]), 0.0)
+    f0 = np.zeros((10, 10)); f1 = f0.copy(); f0[3, 3] = 255; f1[7, 7] = 255
+    fl = S.compute_optical_flow_metric([f0, f1])
+    assert fl.shape == (2,) and fl[0] == 0.0 and fl[1] > 0.0
+
+
+def test_nanmean_and_round():
+    assert S.chunked_nanmean(np.array([1, 2, np.nan, 4, 5.0]), 2) == [1.5, 4.0, 5.0]
+    assert S.estimate_from_counts(1, 2, 5) == 2 and S.estimate_from_counts(1, 2, 7) == 4  # 2.5->2, 3.5->4
+    assert np.isnan(S.estimate_from_counts(3, 0, 7))
+
+
+def test_background_toy_values():                   # ip.compute_background(frames,i,1)
+    toy = np.array([[[1, 5], [5, 1]], [[2, 6], [6, 2]], [[200, 200], [200, 200]],
+                    [[7, 5], [3, 8]], [[3, 1], [4, 5]]], dtype=float)
+    exp = [[[2, 6], [6, 2]], [[100.5, 102.5], [102.5, 100.5]], [[4.5, 5.5], [4.5, 5.0]],
+           [[101.5, 100.5], [102.0, 102.5]], [[7, 5], [3, 8]]]
+    for i in range(5):
+        assert np.array_equal(S.compute_background(toy, i, 1), np.array(exp[i], np.float32))
+
+
+def test_blur_exact_on_flat_and_matches_integer_boxsum():   # SURVEY App. A.3 identity
+    rng = np.random.default_rng(0)
+    f = rng.integers(0, 256, (37, 45)).astype(np.uint8)
+    s = cref.boxsum_u8(f)
+    assert np.array_equal(cref.blur_f64(f, (30, 30)), s.astype(np.float64) * (1.0 / 900.0))
+    for v in (0, 1, 77, 255):
+        flat = np.full((31, 33), v, np.uint8)
+        assert np.all(cref.blur_f64(flat, (30, 30)) == v)
+
+
+def test_ccl_and_morphology_vs_scipy():
+    ndi = pytest.importorskip("scipy.ndimage")
+    rng = np.random.default_rng(1)
+    cross = np.array([[0, 1, 0], [1, 1, 1], [0, 1, 0]], bool)
+    for dens in (0.05, 0.3, 0.6):
+        m = rng.random((41, 57)) < dens
+        n, lab, areas = S.connected_components(m)
+        slab, sn = ndi.label(m, structure=np.ones((3, 3)))
+        assert n == sn + 1
+        # same partition: one-to-one label mapping
+        pairs = set(zip(lab[m].tolist(), slab[m].tolist()))
+        assert len(pairs) == sn
+        assert areas[1:].sum() == m.sum()
+        closed = ndi.binary_erosion(ndi.binary_dilation(m, cross, border_value=0), cross, border_value=1)
+        assert np.array_equal(S.morph_close_cross3(m), closed)
+
+
+def test_contour_perimeter_cases():
+    # hand-traced outer borders (Suzuki-Abe, 8-connected): single pixel, 2-pixel bar, 2x2 and 3x3 squares
+    def per(img):
+        img = np.array(img, bool)
+        ys, xs = np.nonzero(img)
+        return S.contour_perimeter(img, xs[0], ys[0])
+    assert per([[1]]) == 0.0
+    assert per([[1, 1]]) == 2.0                      # there and back
+    assert per([[1, 1], [1, 1]]) == 4.0
+    assert per([[1, 1, 1], [1, 1, 1], [1, 1, 1]]) == 8.0
+    assert per([[1, 0], [0, 1]]) == pytest.approx(2 * S.SQRT2_F32)
+    assert per([[0, 1, 0], [1, 1, 1], [0, 1, 0]]) == pytest.approx(4 * S.SQRT2_F32)
+
+
+def test_perimeter_sum_is_order_independent():
+    # arcLength accumulates float segment lengths (1 or sqrt2 as f32) in a double; the sum is exact,
+    # so perimeter == n_axis + n_diag*sqrt2f whatever the order.  (p**2 via libm pow is NOT always
+    # p*p -- e.g. 13.727921843528748 -- so the product takes p**2 from a host-built table.)
+    rng = np.random.default_rng(0)
+    for _ in range(200):
+        a, d = int(rng.integers(0, 400)), int(rng.integers(0, 400))
+        seg = np.array([1.0] * a + [S.SQRT2_F32] * d)
+        rng.shuffle(seg)
+        acc = 0.0
+        for v in seg:
+            acc += v
+        assert acc == a * 1.0 + d * S.SQRT2_F32
+
+
+def test_f32_mean_equals_double_rounded_mean():
+    # _find_background stores f32(f64 sum / n); the GPU computes the f32 quotient directly.
+    for n in range(1, 17):
+        s = np.arange(0, 255 * n + 1)
+        assert np.array_equal((s.astype(np.float64) / n).astype(np.float32),
+                              s.astype(np.float32) / np.float32(n))
