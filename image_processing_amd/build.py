@@ -1,0 +1,67 @@
+"""Builds image_processing_amd/lib/libipx.so (the C-ABI library, include/ipx.h) with hipcc for gfx950.
+
+Run here on the CPU (hipcc cross-compiles): ``python -m image_processing_amd.build``.
+The library is built in-tree; it is git-ignored but travels to the GPU box with the tree.
+
+Flags that are part of the numerical contract (csrc/detect.hip, csrc/flow.hip):
+``-ffp-contract=off`` (every float op rounds separately, as numpy / numba / OpenCV's scalar
+paths do) and no fast-math (IEEE divide and sqrt).
+"""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIBDIR = os.path.join(HERE, "lib")
+LIB = os.path.join(LIBDIR, "libipx.so")
+SOURCES = ["api.hip", "detect.hip", "temporal.hip", "ccl.hip", "flow.hip", "chunk.hip"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
+         "-fvisibility=hidden", "-Wall", "-Wno-unused-result"]
+
+
+def _hipcc():
+    for cand in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
+        if cand and (os.path.isabs(cand) and os.path.exists(cand) or not os.path.isabs(cand)):
+            return cand
+    return "hipcc"
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build_lib(force=False, verbose=False):
+    """Compile every HIP translation unit to an object (in parallel) and link libipx.so."""
+    os.makedirs(LIBDIR, exist_ok=True)
+    headers = [os.path.join(CSRC, "ipx_internal.h"), os.path.join(HERE, "..", "include", "ipx.h")]
+    objs, procs = [], []
+    for s in SOURCES:
+        src = os.path.join(CSRC, s)
+        obj = os.path.join(LIBDIR, s.replace(".hip", ".o"))
+        objs.append(obj)
+        if force or _stale(obj, [src] + headers):
+            cmd = [_hipcc()] + FLAGS + ["-c", src, "-o", obj]
+            if verbose:
+                print(" ".join(cmd))
+            procs.append((s, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+    for s, p in procs:
+        out, _ = p.communicate()
+        if p.returncode != 0:
+            sys.stderr.write(out.decode(errors="replace"))
+            raise RuntimeError("hipcc failed on %s" % s)
+        if verbose and out:
+            sys.stderr.write(out.decode(errors="replace"))
+    if force or procs or _stale(LIB, objs):
+        cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build_lib(force="--force" in sys.argv, verbose=True))

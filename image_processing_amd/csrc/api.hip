@@ -1,0 +1,238 @@
+// api.hip -- context, error reporting, parameters, small helper kernels of libipx.so.
+#include "ipx_internal.h"
+#include <math.h>
+#include <stdarg.h>
+#include <string.h>
+
+static thread_local char g_err[512] = "";
+
+void ipx_set_error(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" const char *ipx_last_error(void) { return g_err; }
+extern "C" int ipx_version(void) { return 100; }
+
+extern "C" int ipx_device_count(int *count)
+{
+    IPX_REQUIRE(count, "null pointer");
+    IPX_CHECK_HIP(hipGetDeviceCount(count));
+    return IPX_OK;
+}
+
+extern "C" void ipx_default_params(ipx_params *p)
+{
+    if (!p) return;
+    memset(p, 0, sizeof(*p));
+    p->consecutive_threshold = 2;      // ip.py:168
+    p->brightness_threshold = 170;     // ip.py:169
+    p->flow_threshold = 2.0;           // ip.py:170
+    p->static_threshold = 50;          // ip.py:171
+    p->min_cluster_size = 5;           // ip.py:172
+    p->max_cluster_size = 20;          // ip.py:173
+    p->min_circularity = 0.1;          // ip.py:174
+    p->sliding_window_radius = 3;      // ip.py:175
+    p->min_valid_frames = 10;          // ip.py:589
+    p->circularity_size_threshold = 10;  // ip.py:657
+    p->estimate_threshold = 170;       // ip.py:773
+    p->pixel_std_coeff = 1.0;          // ip.py:204
+}
+
+extern "C" int ipx_words_per_row(int W) { return ipx_wpr(W); }
+
+ipx_derived ipx_derive(const ipx_params &p)
+{
+    ipx_derived d;
+    // u8 frame > t  (numpy compares exactly, whatever t's Python type)  <=>  frame > floor(t)
+    double f = floor(p.brightness_threshold);
+    if (f < -1) f = -1;
+    if (f > 255) f = 255;
+    d.frame_gt = (int)f;
+    d.bg_gt = (float)p.brightness_threshold;   // f32 array > weak Python scalar: compared in f32
+    d.est_lt = p.estimate_threshold;
+    return d;
+}
+
+extern "C" int ipx_ctx_create(int device, ipx_ctx **out)
+{
+    IPX_REQUIRE(out, "null pointer");
+    int count = 0;
+    IPX_CHECK_HIP(hipGetDeviceCount(&count));
+    IPX_REQUIRE(device >= 0 && device < count, "no such device");
+    IPX_CHECK_HIP(hipSetDevice(device));
+    ipx_ctx *c = new ipx_ctx();
+    c->device = device;
+    c->stream = nullptr;
+    for (int i = 0; i < SLOT_COUNT; ++i) { c->slot[i] = nullptr; c->slot_bytes[i] = 0; }
+    c->flow_plan = nullptr;
+    ipx_default_params(&c->p);
+    hipError_t e = hipEventCreate(&c->ev0);
+    if (e == hipSuccess) e = hipEventCreate(&c->ev1);
+    if (e != hipSuccess) {
+        delete c;
+        ipx_set_error("hipEventCreate failed: %s", hipGetErrorString(e));
+        return IPX_ERR_HIP;
+    }
+    *out = c;
+    return IPX_OK;
+}
+
+extern "C" int ipx_ctx_destroy(ipx_ctx *ctx)
+{
+    if (!ctx) return IPX_OK;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    for (int i = 0; i < SLOT_COUNT; ++i)
+        if (ctx->slot[i]) (void)hipFree(ctx->slot[i]);
+    ipx_flow_plan_free(ctx->flow_plan);
+    (void)hipEventDestroy(ctx->ev0);
+    (void)hipEventDestroy(ctx->ev1);
+    delete ctx;
+    return IPX_OK;
+}
+
+int ipx_ctx_enter(ipx_ctx *ctx)
+{
+    IPX_CHECK_HIP(hipSetDevice(ctx->device));
+    return IPX_OK;
+}
+
+int ipx_scratch(ipx_ctx *ctx, int s, size_t bytes, void **out)
+{
+    if (bytes == 0) bytes = 256;
+    if (bytes > ctx->slot_bytes[s]) {
+        // growing: everything enqueued so far may still use the old arena
+        IPX_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+        if (ctx->slot[s]) IPX_CHECK_HIP(hipFree(ctx->slot[s]));
+        ctx->slot[s] = nullptr;
+        ctx->slot_bytes[s] = 0;
+        const size_t want = ipx_align_up(bytes + bytes / 16, 1 << 20);
+        hipError_t e = hipMalloc(&ctx->slot[s], want);
+        if (e != hipSuccess) {
+            ipx_set_error("scratch allocation of %zu bytes (slot %d) failed: %s", want, s, hipGetErrorString(e));
+            return IPX_ERR_NOMEM;
+        }
+        ctx->slot_bytes[s] = want;
+    }
+    *out = ctx->slot[s];
+    return IPX_OK;
+}
+
+extern "C" int ipx_set_params(ipx_ctx *ctx, const ipx_params *p)
+{
+    IPX_REQUIRE(ctx && p, "null pointer");
+    ctx->p = *p;
+    return IPX_OK;
+}
+
+extern "C" int ipx_set_stream(ipx_ctx *ctx, void *hip_stream)
+{
+    IPX_REQUIRE(ctx, "null pointer");
+    ctx->stream = (hipStream_t)hip_stream;
+    return IPX_OK;
+}
+
+extern "C" int ipx_synchronize(ipx_ctx *ctx)
+{
+    IPX_REQUIRE(ctx, "null pointer");
+    if (int e = ipx_ctx_enter(ctx)) return e;
+    IPX_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+    return IPX_OK;
+}
+
+extern "C" int ipx_timer_begin(ipx_ctx *ctx)
+{
+    IPX_REQUIRE(ctx, "null pointer");
+    if (int e = ipx_ctx_enter(ctx)) return e;
+    IPX_CHECK_HIP(hipEventRecord(ctx->ev0, ctx->stream));
+    return IPX_OK;
+}
+
+extern "C" int ipx_timer_end(ipx_ctx *ctx, float *elapsed_ms)
+{
+    IPX_REQUIRE(ctx && elapsed_ms, "null pointer");
+    if (int e = ipx_ctx_enter(ctx)) return e;
+    IPX_CHECK_HIP(hipEventRecord(ctx->ev1, ctx->stream));
+    IPX_CHECK_HIP(hipEventSynchronize(ctx->ev1));
+    IPX_CHECK_HIP(hipEventElapsedTime(elapsed_ms, ctx->ev0, ctx->ev1));
+    return IPX_OK;
+}
+
+// ---- helper kernels ------------------------------------------------------------------------
+namespace {
+
+// cv2.cvtColor(BGR2GRAY) on u8, OpenCV 4.x 15-bit fixed point, ip.py:79.
+__global__ void bgr2gray_kernel(const uint8_t *bgr, size_t npix, uint8_t *gray)
+{
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (; i < npix; i += stride) {
+        const unsigned b = bgr[3 * i], g = bgr[3 * i + 1], r = bgr[3 * i + 2];
+        gray[i] = (uint8_t)((b * 3735u + g * 19235u + r * 9798u + 16384u) >> 15);
+    }
+}
+
+// one wave per 64-pixel word: byte mask -> ballot word
+__global__ void pack_kernel(const uint8_t *mask, int rows, int W, int wpr, uint64_t *bits)
+{
+    const int lane = threadIdx.x & 63;
+    const size_t word = (size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (word >= (size_t)rows * wpr) return;
+    const size_t row = word / wpr;
+    const int k = (int)(word - row * wpr);
+    const int x = k * 64 + lane;
+    const bool on = x < W && mask[row * W + x] != 0;
+    const unsigned long long b = __ballot(on);
+    if (lane == 0) bits[word] = b;
+}
+
+__global__ void unpack_kernel(const uint64_t *bits, int rows, int W, int wpr, uint8_t *mask)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)rows * W) return;
+    const size_t row = i / W;
+    const int x = (int)(i - row * W);
+    mask[i] = (bits[row * wpr + (x >> 6)] >> (x & 63)) & 1;
+}
+
+}  // namespace
+
+extern "C" int ipx_bgr2gray(ipx_ctx *ctx, const uint8_t *bgr, size_t npix, uint8_t *gray)
+{
+    IPX_REQUIRE(ctx && bgr && gray, "null pointer");
+    if (npix == 0) return IPX_OK;
+    if (int e = ipx_ctx_enter(ctx)) return e;
+    const int blocks = (int)((npix + 255) / 256 < 4096 ? (npix + 255) / 256 : 4096);
+    hipLaunchKernelGGL(bgr2gray_kernel, dim3(blocks), dim3(256), 0, ctx->stream, bgr, npix, gray);
+    IPX_LAUNCH_CHECK();
+    return IPX_OK;
+}
+
+extern "C" int ipx_pack_mask(ipx_ctx *ctx, const uint8_t *mask, int count, int H, int W, uint64_t *bits)
+{
+    IPX_REQUIRE(ctx && mask && bits, "null pointer");
+    IPX_REQUIRE(count > 0 && H > 0 && W > 0, "bad sizes");
+    if (int e = ipx_ctx_enter(ctx)) return e;
+    const int wpr = ipx_wpr(W);
+    const size_t words = (size_t)count * H * wpr;
+    hipLaunchKernelGGL(pack_kernel, dim3((unsigned)((words + 3) / 4)), dim3(256), 0, ctx->stream, mask,
+                       count * H, W, wpr, bits);
+    IPX_LAUNCH_CHECK();
+    return IPX_OK;
+}
+
+extern "C" int ipx_unpack_mask(ipx_ctx *ctx, const uint64_t *bits, int count, int H, int W, uint8_t *mask)
+{
+    IPX_REQUIRE(ctx && mask && bits, "null pointer");
+    IPX_REQUIRE(count > 0 && H > 0 && W > 0, "bad sizes");
+    if (int e = ipx_ctx_enter(ctx)) return e;
+    const size_t n = (size_t)count * H * W;
+    hipLaunchKernelGGL(unpack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, bits,
+                       count * H, W, ipx_wpr(W), mask);
+    IPX_LAUNCH_CHECK();
+    return IPX_OK;
+}

@@ -1,0 +1,509 @@
+// ccl.hip -- 8-connected component labelling on packed bit-planes, and the two consumers of it:
+//   remove_bright_regions           ip.py:731-767  (2x connectedComponentsWithStats + overlap test)
+//   filter_damaged_pixel_clusters   ip.py:651-728  (close, CCL, size + circularity filter, stats)
+//
+// Labelling unit = a SEGMENT: a maximal run of set bits inside one 64-bit word.  Its id is the
+// padded pixel index of its first bit, id = (word_index << 6) | bit.  One lane owns one word:
+// it links each of its segments to the previous word's last segment (when contiguous) and to
+// the overlapping segments of the three words above (8-connectivity), with a lock-free
+// union-find (atomicMin on the parent array; the smaller id wins, so a component's root is its
+// raster-first pixel -- which is also where OpenCV starts the outer contour).  Every consumer
+// of the reference is invariant to label numbering, so any correct partition
+// is bit-exact at the API.
+#include "ipx_internal.h"
+
+namespace {
+
+struct Plane {
+    int H, W, wpr;
+    size_t words;      // H * wpr
+    size_t ids;        // words * 64 (parent-array entries per plane)
+};
+
+__device__ __forceinline__ int ld_relaxed(const int *p)
+{
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__device__ __forceinline__ int find_root(const int *par, int x)
+{
+    int p;
+    while ((p = ld_relaxed(par + x)) != x) x = p;
+    return x;
+}
+
+__device__ __forceinline__ void unite(int *par, int a, int b)
+{
+    for (;;) {
+        a = find_root(par, a);
+        b = find_root(par, b);
+        if (a == b) return;
+        if (a < b) { const int t = a; a = b; b = t; }
+        const int old = atomicMin(par + a, b);     // link the larger root under the smaller
+        if (old == a) return;
+        a = old;                                     // `a` had been linked meanwhile: carry on
+    }
+}
+
+// lowest segment of `rem` (rem != 0): start bit, length, mask
+__device__ __forceinline__ void first_segment(uint64_t rem, int &s, int &len, uint64_t &mask)
+{
+    s = __builtin_ctzll(rem);
+    const uint64_t inv = ~(rem >> s);               // zeros where the run continues
+    len = inv ? __builtin_ctzll(inv) : 64;
+    if (len > 64 - s) len = 64 - s;
+    mask = (len == 64 ? ~0ull : ((1ull << len) - 1)) << s;
+}
+
+// start bit of the segment of word u that contains bit b (u has bit b set)
+__device__ __forceinline__ int segment_start(uint64_t u, int b)
+{
+    const uint64_t z = ~u & ((1ull << b) - 1);      // zeros below b
+    return z ? 64 - __builtin_clzll(z) : 0;
+}
+
+// start bit of the last segment of u (u has bit 63 set)
+__device__ __forceinline__ int last_segment_start(uint64_t u)
+{
+    const uint64_t z = ~u;
+    return z ? 64 - __builtin_clzll(z) : 0;
+}
+
+// ---- phase 1: every segment its own root; clear the per-root accumulators -----------------------
+__global__ void ccl_init_kernel(const uint64_t *bits, Plane pl, int count, int *par, int *aux0, unsigned *aux1)
+{
+    const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= pl.words * count) return;
+    uint64_t rem = bits[g];
+    if (!rem) return;
+    const size_t plane = g / pl.words;
+    const int w = (int)(g - plane * pl.words);
+    int *pp = par + plane * pl.ids;
+    int *a0 = aux0 + plane * pl.ids;
+    unsigned *a1 = aux1 ? aux1 + plane * pl.ids : nullptr;
+    while (rem) {
+        int s, len; uint64_t m;
+        first_segment(rem, s, len, m);
+        rem &= ~m;
+        const int id = (w << 6) | s;
+        pp[id] = id;
+        a0[id] = 0;
+        if (a1) a1[id] = 0;
+    }
+}
+
+// ---- phase 2: link segments (left word, three words above) --------------------------------------
+__global__ void ccl_merge_kernel(const uint64_t *bits, Plane pl, int count, int *par)
+{
+    const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= pl.words * count) return;
+    const uint64_t wd = bits[g];
+    if (!wd) return;
+    const size_t plane = g / pl.words;
+    const int w = (int)(g - plane * pl.words);
+    const int y = w / pl.wpr, k = w - y * pl.wpr;
+    const uint64_t *bp = bits + plane * pl.words;
+    int *pp = par + plane * pl.ids;
+    const uint64_t left = k > 0 ? bp[w - 1] : 0;
+    uint64_t up = 0, upl = 0, upr = 0;
+    if (y > 0) {
+        up = bp[w - pl.wpr];
+        if (k > 0) upl = bp[w - pl.wpr - 1];
+        if (k + 1 < pl.wpr) upr = bp[w - pl.wpr + 1];
+    }
+    uint64_t rem = wd;
+    while (rem) {
+        int s, len; uint64_t m;
+        first_segment(rem, s, len, m);
+        rem &= ~m;
+        const int e = s + len - 1;
+        const int id = (w << 6) | s;
+        if (s == 0) {
+            if (left >> 63) unite(pp, id, ((w - 1) << 6) | last_segment_start(left));
+            if (upl >> 63) unite(pp, id, ((w - pl.wpr - 1) << 6) | last_segment_start(upl));
+        }
+        if (e == 63 && (upr & 1)) unite(pp, id, (w - pl.wpr + 1) << 6);
+        // bits s-1 .. e+1 of the word above
+        uint64_t range = m | (m << 1) | (m >> 1);
+        uint64_t t = up & range;
+        while (t) {
+            const int b = __builtin_ctzll(t);
+            const int us = segment_start(up, b);
+            int s2, len2; uint64_t m2;
+            first_segment(up >> us << us, s2, len2, m2);     // the whole segment of `up` from us
+            t &= ~m2;
+            unite(pp, id, ((w - pl.wpr) << 6) | us);
+        }
+    }
+}
+
+// ---- remove_bright_regions -----------------------------------------------------------------
+// bright plane: flatten + areas (aux0[root] += segment length)
+__global__ void ccl_area_kernel(const uint64_t *bits, Plane pl, int count, int *par, int *aux0)
+{
+    const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= pl.words * count) return;
+    uint64_t rem = bits[g];
+    if (!rem) return;
+    const size_t plane = g / pl.words;
+    const int w = (int)(g - plane * pl.words);
+    int *pp = par + plane * pl.ids;
+    int *a0 = aux0 + plane * pl.ids;
+    while (rem) {
+        int s, len; uint64_t m;
+        first_segment(rem, s, len, m);
+        rem &= ~m;
+        const int id = (w << 6) | s;
+        const int root = find_root(pp, id);
+        pp[id] = root;
+        atomicAdd(a0 + root, len);
+    }
+}
+
+// out = segments whose component has aux0[root] >= min_area  (the `remove` plane, ip.py:750-754)
+__global__ void select_big_kernel(const uint64_t *bits, Plane pl, int count, const int *par, const int *aux0,
+                                  int min_area, uint64_t *out)
+{
+    const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= pl.words * count) return;
+    uint64_t rem = bits[g];
+    uint64_t r = 0;
+    if (rem) {
+        const size_t plane = g / pl.words;
+        const int w = (int)(g - plane * pl.words);
+        const int *pp = par + plane * pl.ids;
+        const int *a0 = aux0 + plane * pl.ids;
+        while (rem) {
+            int s, len; uint64_t m;
+            first_segment(rem, s, len, m);
+            rem &= ~m;
+            if (a0[pp[(w << 6) | s]] >= min_area) r |= m;
+        }
+    }
+    out[g] = r;
+}
+
+// damaged plane: flatten + taint components that overlap `remove` (ip.py:761-764)
+__global__ void ccl_taint_kernel(const uint64_t *bits, const uint64_t *remove, Plane pl, int count, int *par, int *aux0)
+{
+    const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= pl.words * count) return;
+    uint64_t rem = bits[g];
+    if (!rem) return;
+    const uint64_t rm = remove[g];
+    const size_t plane = g / pl.words;
+    const int w = (int)(g - plane * pl.words);
+    int *pp = par + plane * pl.ids;
+    int *a0 = aux0 + plane * pl.ids;
+    while (rem) {
+        int s, len; uint64_t m;
+        first_segment(rem, s, len, m);
+        rem &= ~m;
+        const int id = (w << 6) | s;
+        const int root = find_root(pp, id);
+        pp[id] = root;
+        if (m & rm) a0[root] = 1;
+    }
+}
+
+__global__ void select_untainted_kernel(const uint64_t *bits, Plane pl, int count, const int *par, const int *aux0,
+                                        uint64_t *out)
+{
+    const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= pl.words * count) return;
+    uint64_t rem = bits[g];
+    uint64_t r = 0;
+    if (rem) {
+        const size_t plane = g / pl.words;
+        const int w = (int)(g - plane * pl.words);
+        const int *pp = par + plane * pl.ids;
+        const int *a0 = aux0 + plane * pl.ids;
+        while (rem) {
+            int s, len; uint64_t m;
+            first_segment(rem, s, len, m);
+            rem &= ~m;
+            if (!a0[pp[(w << 6) | s]]) r |= m;
+        }
+    }
+    out[g] = r;
+}
+
+// ---- filter_damaged_pixel_clusters ----------------------------------------------------------
+// morphologyEx(MORPH_CLOSE, 3x3 cross): dilate (outside = 0) then erode (outside ignored), SURVEY App. A.4
+__device__ __forceinline__ uint64_t mword(const uint64_t *bp, const Plane &pl, int y, int k)
+{
+    return (y >= 0 && y < pl.H && k >= 0 && k < pl.wpr) ? bp[(size_t)y * pl.wpr + k] : 0ull;
+}
+__device__ __forceinline__ uint64_t dilated_word(const uint64_t *bp, const Plane &pl, int y, int k)
+{
+    if (y < 0 || y >= pl.H || k < 0 || k >= pl.wpr) return 0ull;
+    const uint64_t c = mword(bp, pl, y, k);
+    const uint64_t l = mword(bp, pl, y, k - 1), r = mword(bp, pl, y, k + 1);
+    uint64_t d = c | (c << 1) | (l >> 63) | (c >> 1) | (r << 63) | mword(bp, pl, y - 1, k) | mword(bp, pl, y + 1, k);
+    const int valid = pl.W - 64 * k;                 // clip to the image
+    if (valid < 64) d &= (1ull << valid) - 1;
+    return d;
+}
+__global__ void close_cross3_kernel(const uint64_t *bits, Plane pl, int count, const uint8_t *keep, uint64_t *out)
+{
+    const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= pl.words * count) return;
+    const size_t plane = g / pl.words;
+    if (keep && !keep[plane]) { out[g] = 0; return; }
+    const int w = (int)(g - plane * pl.words);
+    const int y = w / pl.wpr, k = w - y * pl.wpr;
+    const uint64_t *bp = bits + plane * pl.words;
+    const uint64_t d = dilated_word(bp, pl, y, k);
+    // erosion: out-of-image neighbours count as set
+    const int valid = pl.W - 64 * k;
+    const uint64_t vmask = valid < 64 ? (1ull << valid) - 1 : ~0ull;
+    const uint64_t dl = k > 0 ? dilated_word(bp, pl, y, k - 1) >> 63 : 1ull;
+    uint64_t dr;
+    if (valid <= 64) dr = 0;                          // right neighbour of the last column is outside
+    else dr = dilated_word(bp, pl, y, k + 1) << 63;
+    uint64_t right = (d >> 1) | dr;
+    if (valid <= 64) right |= 1ull << (valid - 1);   // pixel W-1 looks right at "outside" = set
+    const uint64_t leftn = (d << 1) | dl;
+    const uint64_t upn = y > 0 ? dilated_word(bp, pl, y - 1, k) : ~0ull;
+    const uint64_t dnn = y + 1 < pl.H ? dilated_word(bp, pl, y + 1, k) : ~0ull;
+    out[g] = d & leftn & right & upn & dnn & vmask;
+}
+
+// flatten + per-root area (aux0) and brightness sum (aux1)
+__global__ void cluster_accum_kernel(const uint64_t *bits, const uint8_t *frames, Plane pl, int count, int *par,
+                                     int *aux0, unsigned *aux1)
+{
+    const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= pl.words * count) return;
+    uint64_t rem = bits[g];
+    if (!rem) return;
+    const size_t plane = g / pl.words;
+    const int w = (int)(g - plane * pl.words);
+    const int y = w / pl.wpr, k = w - y * pl.wpr;
+    int *pp = par + plane * pl.ids;
+    const uint8_t *row = frames + (plane * pl.H + y) * (size_t)pl.W + 64 * k;
+    while (rem) {
+        int s, len; uint64_t m;
+        first_segment(rem, s, len, m);
+        rem &= ~m;
+        const int id = (w << 6) | s;
+        const int root = find_root(pp, id);
+        pp[id] = root;
+        unsigned bs = 0;
+        for (int i = 0; i < len; ++i) bs += row[s + i];
+        atomicAdd(aux0 + plane * pl.ids + root, len);
+        atomicAdd(aux1 + plane * pl.ids + root, bs);
+    }
+}
+
+__device__ __forceinline__ int pix_at(const uint64_t *bp, const Plane &pl, int x, int y)
+{
+    if ((unsigned)x >= (unsigned)pl.W || (unsigned)y >= (unsigned)pl.H) return 0;
+    return (int)((bp[(size_t)y * pl.wpr + (x >> 6)] >> (x & 63)) & 1);
+}
+
+// Outer border following from the component's raster-first pixel (findContours RETR_EXTERNAL,
+// CHAIN_APPROX_NONE): returns the number of axis-aligned and diagonal moves (ip.py:691-693).
+__device__ void trace_outer(const uint64_t *bp, const Plane &pl, int x0, int y0, int &n_axis, int &n_diag)
+{
+    const int dx[8] = {1, 1, 0, -1, -1, -1, 0, 1};
+    const int dy[8] = {0, -1, -1, -1, 0, 1, 1, 1};
+    n_axis = 0; n_diag = 0;
+    int s = 4, i1x = x0, i1y = y0;
+    do {
+        s = (s - 1) & 7;
+        i1x = x0 + dx[s]; i1y = y0 + dy[s];
+    } while (!pix_at(bp, pl, i1x, i1y) && s != 4);
+    if (s == 4) return;                               // single pixel: perimeter 0
+    int i3x = x0, i3y = y0, i4x = x0, i4y = y0;
+    for (int guard = 0; guard < (1 << 20); ++guard) {
+        while (s < 15) {
+            ++s;
+            i4x = i3x + dx[s & 7]; i4y = i3y + dy[s & 7];
+            if (pix_at(bp, pl, i4x, i4y)) break;
+        }
+        s &= 7;
+        if (s & 1) ++n_diag; else ++n_axis;
+        if (i4x == x0 && i4y == y0 && i3x == i1x && i3y == i1y) break;
+        i3x = i4x; i3y = i4y;
+        s = (s + 4) & 7;
+    }
+}
+
+struct ClusterArgs {
+    int min_size, max_size, circ_size;
+    float min_circ;
+    const double *pow2; int tdim;
+};
+
+// one lane per word; acts on the segments that are component roots
+__global__ void cluster_eval_kernel(const uint64_t *bits, Plane pl, int count, const int *par, int *aux0,
+                                    const unsigned *aux1, ClusterArgs ca, unsigned long long *stats)
+{
+    const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= pl.words * count) return;
+    uint64_t rem = bits[g];
+    if (!rem) return;
+    const size_t plane = g / pl.words;
+    const int w = (int)(g - plane * pl.words);
+    const int y = w / pl.wpr, k = w - y * pl.wpr;
+    const uint64_t *bp = bits + plane * pl.words;
+    const int *pp = par + plane * pl.ids;
+    while (rem) {
+        int s, len; uint64_t m;
+        first_segment(rem, s, len, m);
+        rem &= ~m;
+        const int id = (w << 6) | s;
+        if (pp[id] != id) continue;
+        const int area = aux0[plane * pl.ids + id];
+        if (area < ca.min_size || area > ca.max_size) continue;      // ip.py:678
+        bool kept = true;
+        if (area >= ca.circ_size) {                                   // ip.py:685-695
+            int na, nd;
+            trace_outer(bp, pl, 64 * k + s, y, na, nd);
+            float circ = 0.f;
+            if (na + nd > 0) {
+                const double per = (double)na + (double)nd * 1.4142135381698608;   // (double)sqrtf(2)
+                const double p2 = (na < ca.tdim && nd < ca.tdim) ? ca.pow2[na * ca.tdim + nd] : per * per;
+                const double q = (double)area / p2;
+                circ = (float)(12.566370614359172 * q);                // 4*np.pi, stored to float32
+            }
+            kept = circ >= ca.min_circ;                                // ip.py:701 (float32 compare)
+        }
+        if (kept) {
+            atomicAdd(stats + plane * 3 + 0, 1ull);
+            atomicAdd(stats + plane * 3 + 1, (unsigned long long)area);
+            atomicAdd(stats + plane * 3 + 2, (unsigned long long)aux1[plane * pl.ids + id]);
+            aux0[plane * pl.ids + id] = -area;                         // mark for the cleaned mask
+        }
+    }
+}
+
+__global__ void select_marked_kernel(const uint64_t *bits, Plane pl, int count, const int *par, const int *aux0,
+                                     uint64_t *out)
+{
+    const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= pl.words * count) return;
+    uint64_t rem = bits[g];
+    uint64_t r = 0;
+    if (rem) {
+        const size_t plane = g / pl.words;
+        const int w = (int)(g - plane * pl.words);
+        const int *pp = par + plane * pl.ids;
+        const int *a0 = aux0 + plane * pl.ids;
+        while (rem) {
+            int s, len; uint64_t m;
+            first_segment(rem, s, len, m);
+            rem &= ~m;
+            if (a0[pp[(w << 6) | s]] < 0) r |= m;
+        }
+    }
+    out[g] = r;
+}
+
+Plane make_plane(int H, int W)
+{
+    Plane pl;
+    pl.H = H; pl.W = W; pl.wpr = ipx_wpr(W);
+    pl.words = (size_t)H * pl.wpr;
+    pl.ids = pl.words * 64;
+    return pl;
+}
+
+// planes per CCL batch so that the scratch stays near `budget` bytes
+int ccl_batch(const Plane &pl, int count, size_t per_plane_bytes, size_t budget)
+{
+    size_t b = budget / per_plane_bytes;
+    if (b < 1) b = 1;
+    if (b > (size_t)count) b = count;
+    return (int)b;
+}
+
+constexpr size_t CCL_BUDGET = (size_t)1 << 30;
+
+}  // namespace
+
+extern "C" int ipx_remove_bright_regions(ipx_ctx *ctx, const uint64_t *bright_bits, const uint64_t *damaged_bits,
+                                         int count, int H, int W, uint64_t *out_bits)
+{
+    IPX_REQUIRE(ctx && bright_bits && damaged_bits && out_bits, "null pointer");
+    IPX_REQUIRE(count > 0 && H > 0 && W > 0, "bad sizes");
+    IPX_REQUIRE((size_t)H * ipx_wpr(W) * 64 < ((size_t)1 << 31), "frame too large for 32-bit segment ids");
+    if (int e = ipx_ctx_enter(ctx)) return e;
+    const Plane pl = make_plane(H, W);
+    // per plane: parent + aux0 (int32 per id) + one `remove` plane
+    const size_t per_plane = pl.ids * 8 + pl.words * 8;
+    const int B = ccl_batch(pl, count, per_plane, CCL_BUDGET);
+    void *scr;
+    if (int e = ipx_scratch(ctx, SLOT_CCL, per_plane * B, &scr)) return e;
+    int *par = (int *)scr;
+    int *aux0 = par + pl.ids * B;
+    uint64_t *remove = (uint64_t *)(aux0 + pl.ids * B);
+    const int min_area = ctx->p.max_cluster_size;
+    for (int first = 0; first < count; first += B) {
+        const int nb = count - first < B ? count - first : B;
+        const uint64_t *bb = bright_bits + first * pl.words;
+        const uint64_t *db = damaged_bits + first * pl.words;
+        uint64_t *ob = out_bits + first * pl.words;
+        const size_t nw = pl.words * nb;
+        const dim3 grid((unsigned)((nw + 255) / 256)), block(256);
+        hipLaunchKernelGGL(ccl_init_kernel, grid, block, 0, ctx->stream, bb, pl, nb, par, aux0, (unsigned *)nullptr);
+        hipLaunchKernelGGL(ccl_merge_kernel, grid, block, 0, ctx->stream, bb, pl, nb, par);
+        hipLaunchKernelGGL(ccl_area_kernel, grid, block, 0, ctx->stream, bb, pl, nb, par, aux0);
+        hipLaunchKernelGGL(select_big_kernel, grid, block, 0, ctx->stream, bb, pl, nb, par, aux0, min_area, remove);
+        hipLaunchKernelGGL(ccl_init_kernel, grid, block, 0, ctx->stream, db, pl, nb, par, aux0, (unsigned *)nullptr);
+        hipLaunchKernelGGL(ccl_merge_kernel, grid, block, 0, ctx->stream, db, pl, nb, par);
+        hipLaunchKernelGGL(ccl_taint_kernel, grid, block, 0, ctx->stream, db, remove, pl, nb, par, aux0);
+        hipLaunchKernelGGL(select_untainted_kernel, grid, block, 0, ctx->stream, db, pl, nb, par, aux0, ob);
+        IPX_LAUNCH_CHECK();
+    }
+    return IPX_OK;
+}
+
+extern "C" int ipx_cluster_stats(ipx_ctx *ctx, const uint8_t *frames, const uint64_t *mask_bits, const uint8_t *keep,
+                                 int n, int H, int W, const double *pow2_table, int tdim,
+                                 int64_t *stats, uint64_t *cleaned_bits)
+{
+    IPX_REQUIRE(ctx && frames && mask_bits && stats, "null pointer");
+    IPX_REQUIRE(n > 0 && H > 0 && W > 0, "bad sizes");
+    IPX_REQUIRE(pow2_table == nullptr || tdim > 0, "bad pow2 table");
+    IPX_REQUIRE((size_t)H * ipx_wpr(W) * 64 < ((size_t)1 << 31), "frame too large for 32-bit segment ids");
+    if (int e = ipx_ctx_enter(ctx)) return e;
+    const Plane pl = make_plane(H, W);
+    // per plane: parent + aux0 + aux1 (4 bytes per id each) + the closed plane
+    const size_t per_plane = pl.ids * 12 + pl.words * 8;
+    const int B = ccl_batch(pl, n, per_plane, CCL_BUDGET);
+    void *scr;
+    if (int e = ipx_scratch(ctx, SLOT_CCL, per_plane * B, &scr)) return e;
+    int *par = (int *)scr;
+    int *aux0 = par + pl.ids * B;
+    unsigned *aux1 = (unsigned *)(aux0 + pl.ids * B);
+    uint64_t *closed = (uint64_t *)(aux1 + pl.ids * B);
+    ClusterArgs ca;
+    ca.min_size = ctx->p.min_cluster_size;
+    ca.max_size = ctx->p.max_cluster_size;
+    ca.circ_size = ctx->p.circularity_size_threshold;
+    ca.min_circ = (float)ctx->p.min_circularity;
+    ca.pow2 = pow2_table;
+    ca.tdim = pow2_table ? tdim : 0;
+    IPX_CHECK_HIP(hipMemsetAsync(stats, 0, sizeof(int64_t) * 3 * (size_t)n, ctx->stream));
+    for (int first = 0; first < n; first += B) {
+        const int nb = n - first < B ? n - first : B;
+        const uint64_t *mb = mask_bits + first * pl.words;
+        const uint8_t *fr = frames + (size_t)first * H * W;
+        const uint8_t *kp = keep ? keep + first : nullptr;
+        const size_t nw = pl.words * nb;
+        const dim3 grid((unsigned)((nw + 255) / 256)), block(256);
+        hipLaunchKernelGGL(close_cross3_kernel, grid, block, 0, ctx->stream, mb, pl, nb, kp, closed);
+        hipLaunchKernelGGL(ccl_init_kernel, grid, block, 0, ctx->stream, closed, pl, nb, par, aux0, aux1);
+        hipLaunchKernelGGL(ccl_merge_kernel, grid, block, 0, ctx->stream, closed, pl, nb, par);
+        hipLaunchKernelGGL(cluster_accum_kernel, grid, block, 0, ctx->stream, closed, fr, pl, nb, par, aux0, aux1);
+        hipLaunchKernelGGL(cluster_eval_kernel, grid, block, 0, ctx->stream, closed, pl, nb, par, aux0, aux1, ca,
+                           (unsigned long long *)stats + (size_t)first * 3);
+        if (cleaned_bits)
+            hipLaunchKernelGGL(select_marked_kernel, grid, block, 0, ctx->stream, closed, pl, nb, par, aux0,
+                               cleaned_bits + first * pl.words);
+        IPX_LAUNCH_CHECK();
+    }
+    return IPX_OK;
+}

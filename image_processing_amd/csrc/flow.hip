@@ -1,0 +1,705 @@
+// flow.hip -- the frame-difference motion test: dense Farneback flow between consecutive frames
+// and its mean magnitude (gfx950).
+//
+// Replaces compute_optical_flow_metric, ip.py:852-873:
+//   cv2.calcOpticalFlowFarneback(prev, curr, None, 0.5, 3, 15, 3, 5, 2, 0)   ip.py:858-867
+//   np.mean(cv2.cartToPolar(fx, fy)[0])                                      ip.py:868
+// and the discard rule `flow <= flow_threshold` of ip.py:559.
+//
+// The arithmetic follows the published OpenCV algorithm as SURVEY.md App. A.6 specifies it
+// (pyramid = Gaussian blur of the full-resolution frame + linear resize; polynomial expansion
+// with 11-tap separable filters, vertical pass in f32, horizontal pass in f64; matrix update with
+// a bilinear sample of the second expansion and border damping; 15x15 box window in f64 and a
+// regularised 2x2 solve).  Every per-pixel expression is evaluated with the same types and
+// operation order (no FMA contraction); two reductions are re-associated for parallelism and
+// stay inside the 1e-5 relative tolerance of the float metric: the 15x15 window (direct f64
+// sums instead of running sums) and the mean magnitude (f64 tree instead of numpy's f32
+// pairwise sum).
+//
+// MI355X design: a batch of B consecutive pairs is processed per launch (grid.z = frame or
+// pair) so that the coarse pyramid levels still fill 256 CUs; the polynomial expansion of a
+// frame is computed once and serves both pairs it belongs to; expansions and matrices are
+// planar ([channel][y][x]) so that every wave reads and writes contiguous 256-byte rows.
+#include "ipx_internal.h"
+#include <math.h>
+#include <float.h>
+#include <string.h>
+#include <vector>
+
+namespace {
+
+constexpr int MAX_LEVELS = 8;
+constexpr int POLY_N = 5;
+constexpr int MAX_KS = 31;
+
+struct LevelGeom {
+    int lh, lw;          // level size
+    int ksize;           // Gaussian aperture (odd)
+    int mode;            // 0 = same size (copy), 1 = exact 2x2 area average, 2 = two-tap linear
+    float kern[MAX_KS];  // Gaussian taps, f32
+    // device tables (inside SLOT_FLOW_TAB)
+    const int *x_ofs;    // [lw]  source column of the first tap
+    const float *x_a;    // [lw]  weight of the second tap
+    const int *y_ofs;    // [lh][2] clamped source rows
+    const float *y_b;    // [lh]  weight of the second row
+    // upsampling of the previous (coarser) level's flow to this level
+    const int *ux_ofs; const float *ux_a; const int *uy_ofs; const float *uy_b;
+};
+
+struct PolyConst {
+    float g[POLY_N + 1], xg[POLY_N + 1], xxg[POLY_N + 1];
+    double ig11, ig03, ig33, ig55;
+};
+
+}  // namespace
+
+struct ipx_flow_plan {
+    int H, W, levels;               // levels = index of the coarsest level (0 = full resolution only)
+    LevelGeom lv[MAX_LEVELS];
+    PolyConst pc;
+};
+
+void ipx_flow_plan_free(ipx_flow_plan *plan) { delete plan; }
+
+namespace {
+
+inline int cv_round(double v) { return (int)lrint(v); }
+inline int cv_floor(double v) { return (int)floor(v); }
+
+// getGaussianKernel(n, sigma, CV_32F)
+void gaussian_kernel(int n, double sigma, float *k)
+{
+    static const double small3[3] = {0.25, 0.5, 0.25};
+    static const double small5[5] = {0.0625, 0.25, 0.375, 0.25, 0.0625};
+    static const double small7[7] = {0.03125, 0.109375, 0.21875, 0.28125, 0.21875, 0.109375, 0.03125};
+    if (sigma <= 0 && (n == 1 || n == 3 || n == 5 || n == 7)) {
+        if (n == 1) { k[0] = 1.f; return; }
+        const double *t = n == 3 ? small3 : n == 5 ? small5 : small7;
+        for (int i = 0; i < n; ++i) k[i] = (float)t[i];
+        return;
+    }
+    const double sg = sigma > 0 ? sigma : ((n - 1) * 0.5 - 1) * 0.3 + 0.8;
+    const double scale2 = -0.5 / (sg * sg);
+    double tmp[MAX_KS], sum = 0.0;
+    for (int i = 0; i < n; ++i) {
+        const double x = i - (n - 1) * 0.5;
+        tmp[i] = exp(scale2 * x * x);
+        sum += tmp[i];
+    }
+    sum = 1.0 / sum;
+    for (int i = 0; i < n; ++i) k[i] = (float)(tmp[i] * sum);
+}
+
+// FarnebackPrepareGaussian: taps and the inverse Gram entries (closed-form block inverse)
+void poly_prepare(int n, double sigma, PolyConst &pc)
+{
+    if (sigma < FLT_EPSILON) sigma = n * 0.3;
+    float gb[2 * POLY_N + 1], xgb[2 * POLY_N + 1], xxgb[2 * POLY_N + 1];
+    float *g = gb + n, *xg = xgb + n, *xxg = xxgb + n;
+    double s = 0.0;
+    for (int x = -n; x <= n; ++x) {
+        g[x] = (float)exp(-x * x / (2 * sigma * sigma));
+        s += g[x];
+    }
+    s = 1.0 / s;
+    for (int x = -n; x <= n; ++x) {
+        g[x] = (float)(g[x] * s);
+        xg[x] = (float)(x * g[x]);
+        xxg[x] = (float)(x * x * g[x]);
+    }
+    double G00 = 0, G11 = 0, G33 = 0, G55 = 0;
+    for (int y = -n; y <= n; ++y)
+        for (int x = -n; x <= n; ++x) {
+            G00 += g[y] * g[x];
+            G11 += g[y] * g[x] * x * x;
+            G33 += g[y] * g[x] * x * x * x * x;
+            G55 += g[y] * g[x] * x * x * y * y;
+        }
+    const double a = G00, b = G11, c = G33, d = G55;
+    const double det = a * (c * c - d * d) - 2.0 * b * b * (c - d);
+    pc.ig11 = 1.0 / G11;
+    pc.ig03 = (b * d - b * c) / det;
+    pc.ig33 = (a * c - b * b) / det;
+    pc.ig55 = 1.0 / G55;
+    for (int k = 0; k <= n; ++k) { pc.g[k] = g[k]; pc.xg[k] = xg[k]; pc.xxg[k] = xxg[k]; }
+}
+
+// cv::resize(INTER_LINEAR) coordinate tables for one axis: dst length dn from src length sn.
+void linear_table_x(int sn, int dn, std::vector<int> &ofs, std::vector<float> &a)
+{
+    const double scale = 1.0 / ((double)dn / sn);
+    ofs.resize(dn); a.resize(dn);
+    for (int d = 0; d < dn; ++d) {
+        float f = (float)((d + 0.5) * scale - 0.5);
+        int s = cv_floor(f);
+        f -= s;
+        if (s < 0) { f = 0; s = 0; }
+        if (s >= sn - 1) { f = 0; s = sn - 1; }
+        ofs[d] = s; a[d] = f;
+    }
+}
+void linear_table_y(int sn, int dn, std::vector<int> &ofs2, std::vector<float> &b)
+{
+    const double scale = 1.0 / ((double)dn / sn);
+    ofs2.resize(2 * (size_t)dn); b.resize(dn);
+    for (int d = 0; d < dn; ++d) {
+        float f = (float)((d + 0.5) * scale - 0.5);
+        const int s = cv_floor(f);
+        f -= s;
+        ofs2[2 * d] = s < 0 ? 0 : (s > sn - 1 ? sn - 1 : s);
+        ofs2[2 * d + 1] = s + 1 < 0 ? 0 : (s + 1 > sn - 1 ? sn - 1 : s + 1);
+        b[d] = f;
+    }
+}
+
+__device__ __forceinline__ int reflect101(int p, int len)
+{
+    if (len == 1) return 0;
+    while ((unsigned)p >= (unsigned)len) p = p < 0 ? -p : 2 * (len - 1) - p;
+    return p;
+}
+
+struct KernTaps { float k[MAX_KS]; };
+
+// GaussianBlur(frame as f32, (KS,KS), sigma) at one full-resolution position, BORDER_REFLECT_101:
+// row pass then column pass in f32, tap order as the separable filter engine evaluates it
+// (symmetric pairing for apertures <= 5 in the row pass, left-to-right otherwise; symmetric
+// pairing from the centre outwards in the column pass).
+template <int KS>
+__device__ __forceinline__ float row_pass(const uint8_t *row, int x, int W, const KernTaps &kt)
+{
+    constexpr int R = KS / 2;
+    float s;
+    if (KS <= 5) {
+        s = (float)row[x] * kt.k[R];
+#pragma unroll
+        for (int j = 1; j <= R; ++j)
+            s += ((float)row[reflect101(x - j, W)] + (float)row[reflect101(x + j, W)]) * kt.k[R + j];
+    } else {
+        s = (float)row[reflect101(x - R, W)] * kt.k[0];
+#pragma unroll
+        for (int i = 1; i < KS; ++i) s += (float)row[reflect101(x - R + i, W)] * kt.k[i];
+    }
+    return s;
+}
+
+template <int KS>
+__device__ __forceinline__ float blurred_at(const uint8_t *frame, int y, int x, int H, int W, const KernTaps &kt)
+{
+    constexpr int R = KS / 2;
+    float s = kt.k[R] * row_pass<KS>(frame + (size_t)y * W, x, W, kt);
+#pragma unroll 1
+    for (int j = 1; j <= R; ++j) {
+        const float lo = row_pass<KS>(frame + (size_t)reflect101(y + j, H) * W, x, W, kt);
+        const float hi = row_pass<KS>(frame + (size_t)reflect101(y - j, H) * W, x, W, kt);
+        s += kt.k[R + j] * (lo + hi);
+    }
+    return s;
+}
+
+struct PyrArgs {
+    const uint8_t *frames;     // frame f of this launch = frames + frame_index(f) * H * W
+    const uint8_t *extra;      // optional frame standing in for index -1 (left halo), may be null
+    int first;                 // chunk index of launch frame 0 (may be -1 when `extra` is given)
+    int H, W, lh, lw, mode;
+    const int *x_ofs; const float *x_a; const int *y_ofs; const float *y_b;
+    float *out;                // [nf][lh][lw]
+    KernTaps kt;
+};
+
+// One thread per level pixel: blur at the 1, 4 (area) or 4 (linear) source positions it needs.
+template <int KS>
+__global__ __launch_bounds__(256) void pyr_level_kernel(PyrArgs a)
+{
+    const int dx = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int dy = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (dx >= a.lw || dy >= a.lh) return;
+    const int f = blockIdx.z;
+    const int fi = a.first + f;
+    const uint8_t *frame = fi < 0 ? a.extra : a.frames + (size_t)fi * a.H * a.W;
+    float v;
+    if (a.mode == 0) {
+        v = blurred_at<KS>(frame, dy, dx, a.H, a.W, a.kt);
+    } else if (a.mode == 1) {
+        const float s00 = blurred_at<KS>(frame, 2 * dy, 2 * dx, a.H, a.W, a.kt);
+        const float s01 = blurred_at<KS>(frame, 2 * dy, 2 * dx + 1, a.H, a.W, a.kt);
+        const float s10 = blurred_at<KS>(frame, 2 * dy + 1, 2 * dx, a.H, a.W, a.kt);
+        const float s11 = blurred_at<KS>(frame, 2 * dy + 1, 2 * dx + 1, a.H, a.W, a.kt);
+        v = (s00 + s01 + s10 + s11) * 0.25f;
+    } else {
+        const int sx = a.x_ofs[dx];
+        const float a1 = a.x_a[dx], a0 = 1.f - a1;
+        const int y0 = a.y_ofs[2 * dy], y1 = a.y_ofs[2 * dy + 1];
+        const float b1 = a.y_b[dy], b0 = 1.f - b1;
+        float h0, h1;
+        if (sx >= a.W - 1) {
+            h0 = blurred_at<KS>(frame, y0, sx, a.H, a.W, a.kt);
+            h1 = blurred_at<KS>(frame, y1, sx, a.H, a.W, a.kt);
+        } else {
+            h0 = blurred_at<KS>(frame, y0, sx, a.H, a.W, a.kt) * a0 + blurred_at<KS>(frame, y0, sx + 1, a.H, a.W, a.kt) * a1;
+            h1 = blurred_at<KS>(frame, y1, sx, a.H, a.W, a.kt) * a0 + blurred_at<KS>(frame, y1, sx + 1, a.H, a.W, a.kt) * a1;
+        }
+        v = h0 * b0 + h1 * b1;
+    }
+    a.out[((size_t)f * a.lh + dy) * a.lw + dx] = v;
+}
+
+// FarnebackPolyExp: I [nf][h][w] -> R [nf][5][h][w].  Block = 64 columns x 4 rows; the vertical
+// pass (f32) of 64+10 columns is staged in LDS, the horizontal pass accumulates in f64.
+constexpr int PX_TW = 64, PX_TH = 4;
+__global__ __launch_bounds__(256) void polyexp_kernel(const float *I, int h, int w, PolyConst pc, float *R)
+{
+    __shared__ float s_row[PX_TH][3][PX_TW + 2 * POLY_N + 2];
+    const int lane = threadIdx.x & 63, ry = threadIdx.x >> 6;
+    const int x0 = blockIdx.x * PX_TW;
+    const int y = blockIdx.y * PX_TH + ry;
+    const size_t f = blockIdx.z;
+    const float *img = I + f * (size_t)h * w;
+    if (y < h) {
+        for (int c = lane; c < PX_TW + 2 * POLY_N; c += 64) {
+            int x = x0 - POLY_N + c;
+            x = x < 0 ? 0 : (x > w - 1 ? w - 1 : x);          // replicated vertical-pass columns
+            float t0 = img[(size_t)y * w + x] * pc.g[0], t1 = 0.f, t2 = 0.f;
+#pragma unroll
+            for (int k = 1; k <= POLY_N; ++k) {
+                const float s0 = img[(size_t)(y - k < 0 ? 0 : y - k) * w + x];
+                const float s1 = img[(size_t)(y + k > h - 1 ? h - 1 : y + k) * w + x];
+                const float p = s0 + s1;
+                t0 = t0 + pc.g[k] * p;
+                t1 = t1 + pc.xg[k] * (s1 - s0);
+                t2 = t2 + pc.xxg[k] * p;
+            }
+            s_row[ry][0][c] = t0; s_row[ry][1][c] = t1; s_row[ry][2][c] = t2;
+        }
+    }
+    __syncthreads();
+    const int x = x0 + lane;
+    if (y >= h || x >= w) return;
+    const float *r0 = s_row[ry][0] + lane + POLY_N, *r1 = s_row[ry][1] + lane + POLY_N, *r2 = s_row[ry][2] + lane + POLY_N;
+    double b1 = r0[0] * pc.g[0], b2 = 0, b3 = r1[0] * pc.g[0], b4 = 0, b5 = r2[0] * pc.g[0], b6 = 0;
+#pragma unroll
+    for (int k = 1; k <= POLY_N; ++k) {
+        const double tg = r0[k] + r0[-k];
+        const float g0 = pc.g[k];
+        b1 += tg * g0; b4 += tg * pc.xxg[k];
+        b2 += (r0[k] - r0[-k]) * pc.xg[k];
+        b3 += (r1[k] + r1[-k]) * g0;
+        b6 += (r1[k] - r1[-k]) * pc.xg[k];
+        b5 += (r2[k] + r2[-k]) * g0;
+    }
+    const size_t P = (size_t)h * w;
+    float *o = R + f * 5 * P + (size_t)y * w + x;
+    o[0] = (float)(b3 * pc.ig11);
+    o[P] = (float)(b2 * pc.ig11);
+    o[2 * P] = (float)(b1 * pc.ig03 + b5 * pc.ig33);
+    o[3 * P] = (float)(b1 * pc.ig03 + b4 * pc.ig33);
+    o[4 * P] = (float)(b6 * pc.ig55);
+}
+
+// flow of the next finer level = linear resize of the coarser flow, times 1/pyr_scale (= 2)
+__global__ void flow_upsample_kernel(const float2 *src, int sh, int sw, float2 *dst, int dh, int dw,
+                                     const int *x_ofs, const float *x_a, const int *y_ofs, const float *y_b)
+{
+    const int dx = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int dy = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (dx >= dw || dy >= dh) return;
+    const size_t p = blockIdx.z;
+    const float2 *S0 = src + (p * sh + y_ofs[2 * dy]) * (size_t)sw;
+    const float2 *S1 = src + (p * sh + y_ofs[2 * dy + 1]) * (size_t)sw;
+    const int sx = x_ofs[dx];
+    const float a1 = x_a[dx], a0 = 1.f - a1, b1 = y_b[dy], b0 = 1.f - b1;
+    float2 h0, h1;
+    if (sx >= sw - 1) {
+        h0 = S0[sx]; h1 = S1[sx];
+    } else {
+        const float2 p00 = S0[sx], p01 = S0[sx + 1], p10 = S1[sx], p11 = S1[sx + 1];
+        h0.x = p00.x * a0 + p01.x * a1; h0.y = p00.y * a0 + p01.y * a1;
+        h1.x = p10.x * a0 + p11.x * a1; h1.y = p10.y * a0 + p11.y * a1;
+    }
+    float2 o;
+    o.x = (h0.x * b0 + h1.x * b1) * 2.0f;
+    o.y = (h0.y * b0 + h1.y * b1) * 2.0f;
+    dst[(p * dh + dy) * (size_t)dw + dx] = o;
+}
+
+// FarnebackUpdateMatrices: pair p uses the expansions of launch frames p (R0) and p+1 (R1).
+__global__ __launch_bounds__(256) void update_matrices_kernel(const float *R, const float2 *flow, int h, int w, float *M)
+{
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= w || y >= h) return;
+    const size_t p = blockIdx.z;
+    const size_t P = (size_t)h * w;
+    const float *R0 = R + p * 5 * P, *R1 = R0 + 5 * P;
+    const size_t o = (size_t)y * w + x;
+    const float2 d = flow[p * P + o];
+    const float dx = d.x, dy = d.y;
+    float fx = x + dx, fy = y + dy;
+    const int x1 = (int)floorf(fx), y1 = (int)floorf(fy);
+    float r2, r3, r4, r5, r6;
+    fx -= x1; fy -= y1;
+    if ((unsigned)x1 < (unsigned)(w - 1) && (unsigned)y1 < (unsigned)(h - 1)) {
+        const float *q = R1 + (size_t)y1 * w + x1;
+        const float a00 = (1.f - fx) * (1.f - fy), a01 = fx * (1.f - fy), a10 = (1.f - fx) * fy, a11 = fx * fy;
+        r2 = a00 * q[0] + a01 * q[1] + a10 * q[w] + a11 * q[w + 1];
+        q += P; r3 = a00 * q[0] + a01 * q[1] + a10 * q[w] + a11 * q[w + 1];
+        q += P; r4 = a00 * q[0] + a01 * q[1] + a10 * q[w] + a11 * q[w + 1];
+        q += P; r5 = a00 * q[0] + a01 * q[1] + a10 * q[w] + a11 * q[w + 1];
+        q += P; r6 = a00 * q[0] + a01 * q[1] + a10 * q[w] + a11 * q[w + 1];
+        r4 = (R0[2 * P + o] + r4) * 0.5f;
+        r5 = (R0[3 * P + o] + r5) * 0.5f;
+        r6 = (R0[4 * P + o] + r6) * 0.25f;
+    } else {
+        r2 = r3 = 0.f;
+        r4 = R0[2 * P + o];
+        r5 = R0[3 * P + o];
+        r6 = R0[4 * P + o] * 0.5f;
+    }
+    r2 = (R0[o] - r2) * 0.5f;
+    r3 = (R0[P + o] - r3) * 0.5f;
+    r2 += r4 * dy + r6 * dx;
+    r3 += r6 * dy + r5 * dx;
+    constexpr int BORDER = 5;
+    if ((unsigned)(x - BORDER) >= (unsigned)(w - BORDER * 2) || (unsigned)(y - BORDER) >= (unsigned)(h - BORDER * 2)) {
+        const float border[BORDER] = {0.14f, 0.14f, 0.4472f, 0.4472f, 0.4472f};
+        auto bw = [&](int i) -> float {   // border[i], 0 <= i < 5, without a runtime-indexed array
+            return i < 2 ? 0.14f : 0.4472f;
+        };
+        (void)border;
+        const float scale = (x < BORDER ? bw(x) : 1.f) * (x >= w - BORDER ? bw(w - x - 1) : 1.f) *
+                            (y < BORDER ? bw(y) : 1.f) * (y >= h - BORDER ? bw(h - y - 1) : 1.f);
+        r2 *= scale; r3 *= scale; r4 *= scale; r5 *= scale; r6 *= scale;
+    }
+    float *m = M + p * 5 * P + o;
+    m[0] = r4 * r4 + r6 * r6;
+    m[P] = (r4 + r5) * r6;
+    m[2 * P] = r5 * r5 + r6 * r6;
+    m[3 * P] = r4 * r2 + r6 * r3;
+    m[4 * P] = r6 * r2 + r5 * r3;
+}
+
+// FarnebackUpdateFlow_Blur's box window + solve: M [np][5][h][w] -> flow [np][h][w] (float2).
+// Tile = 64 x 16 outputs; vertical 15-sums (f64, sliding) of 78 columns are staged in LDS, each
+// thread then slides a horizontal 15-window over 4 consecutive outputs.  Replicate borders.
+constexpr int BS_TW = 64, BS_TH = 16, BS_M = 7, BS_COLS = BS_TW + 2 * BS_M;   // winsize 15
+__global__ __launch_bounds__(256) void blur_solve_kernel(const float *M, int h, int w, float2 *flow)
+{
+    __shared__ double s_v[5][BS_TH][BS_COLS + 1];
+    const int tid = threadIdx.x;
+    const int x0 = blockIdx.x * BS_TW, y0 = blockIdx.y * BS_TH;
+    const size_t p = blockIdx.z;
+    const size_t P = (size_t)h * w;
+    const float *Mp = M + p * 5 * P;
+    for (int item = tid; item < 5 * BS_COLS; item += 256) {
+        const int ch = item / BS_COLS, c = item - ch * BS_COLS;
+        int x = x0 - BS_M + c;
+        x = x < 0 ? 0 : (x > w - 1 ? w - 1 : x);
+        const float *col = Mp + ch * P + x;
+        auto at = [&](int yy) -> double {
+            yy = yy < 0 ? 0 : (yy > h - 1 ? h - 1 : yy);
+            return (double)col[(size_t)yy * w];
+        };
+        double s = 0.0;
+#pragma unroll
+        for (int i = -BS_M; i <= BS_M; ++i) s += at(y0 + i);
+        s_v[ch][0][c] = s;
+#pragma unroll 5
+        for (int r = 1; r < BS_TH; ++r) {
+            s += at(y0 + r + BS_M) - at(y0 + r - BS_M - 1);
+            s_v[ch][r][c] = s;
+        }
+    }
+    __syncthreads();
+    const int r = tid >> 4, xq = (tid & 15) * 4;
+    const int y = y0 + r;
+    if (y >= h) return;
+    double acc[5][4];
+#pragma unroll
+    for (int ch = 0; ch < 5; ++ch) {
+        const double *v = s_v[ch][r] + xq;
+        double s = 0.0;
+#pragma unroll
+        for (int i = 0; i < 2 * BS_M + 1; ++i) s += v[i];
+        acc[ch][0] = s;
+#pragma unroll
+        for (int j = 1; j < 4; ++j) {
+            s += v[j + 2 * BS_M] - v[j - 1];
+            acc[ch][j] = s;
+        }
+    }
+    const double scale = 1.0 / (double)((2 * BS_M + 1) * (2 * BS_M + 1));
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int x = x0 + xq + j;
+        if (x < w) {
+            const double g11 = acc[0][j] * scale, g12 = acc[1][j] * scale, g22 = acc[2][j] * scale,
+                         h1 = acc[3][j] * scale, h2 = acc[4][j] * scale;
+            const double idet = 1. / (g11 * g22 - g12 * g12 + 1e-3);
+            float2 o;
+            o.x = (float)((g11 * h2 - g12 * h1) * idet);
+            o.y = (float)((g22 * h1 - g12 * h2) * idet);
+            flow[p * P + (size_t)y * w + x] = o;
+        }
+    }
+}
+
+// mean magnitude: per-pair partial sums (f64) in a fixed order, then one finishing block per pair
+constexpr int RED_BLOCKS = 64;
+__global__ __launch_bounds__(256) void magnitude_partial_kernel(const float2 *flow, size_t P, double *partial)
+{
+    __shared__ double s_w[4];
+    const size_t p = blockIdx.y;
+    const float2 *f = flow + p * P;
+    double s = 0.0;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < P; i += (size_t)RED_BLOCKS * 256) {
+        const float2 v = f[i];
+        s += (double)sqrtf(v.x * v.x + v.y * v.y);      // cartToPolar magnitude in f32, ip.py:868
+    }
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off);
+    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[p * RED_BLOCKS + blockIdx.x] = (s_w[0] + s_w[1]) + (s_w[2] + s_w[3]);
+}
+
+__global__ void magnitude_finish_kernel(const double *partial, size_t P, int npairs, double thr, float *flows, uint8_t *keep)
+{
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= npairs) return;
+    double s = 0.0;
+    for (int i = 0; i < RED_BLOCKS; ++i) s += partial[(size_t)p * RED_BLOCKS + i];
+    const float m = (float)(s / (double)P);                // np.mean of an f32 array is f32
+    flows[p] = m;
+    if (keep) keep[p] = (double)m <= thr;                  // ip.py:559 (NaN compares false: discarded)
+}
+
+__global__ void first_frame_kernel(float *flows, uint8_t *keep)
+{
+    flows[0] = 0.f;                                        // ip.py:853: optical_flows[0] = 0
+    if (keep) keep[0] = 1;
+}
+
+// ------------------------------------------------------------------------------------------------
+int build_plan(ipx_ctx *ctx, int H, int W)
+{
+    if (ctx->flow_plan && ctx->flow_plan->H == H && ctx->flow_plan->W == W) return IPX_OK;
+    IPX_CHECK_HIP(hipStreamSynchronize(ctx->stream));       // tables of the old plan may be in use
+    ipx_flow_plan_free(ctx->flow_plan);
+    ctx->flow_plan = nullptr;
+    ipx_flow_plan *pl = new ipx_flow_plan();
+    pl->H = H; pl->W = W;
+    const double pyr_scale = 0.5;
+    int levels = 3;                                         // ip.py:862
+    {
+        double scale = 1; int k;
+        for (k = 0; k < levels; ++k) {
+            scale *= pyr_scale;
+            if (W * scale < 32 || H * scale < 32) break;
+        }
+        levels = k;
+    }
+    pl->levels = levels;
+    poly_prepare(POLY_N, 2.0, pl->pc);                      // ip.py:865-866
+    std::vector<char> host;
+    auto push = [&](const void *src, size_t bytes) -> size_t {
+        const size_t off = ipx_align_up(host.size(), 16);
+        host.resize(off + bytes);
+        memcpy(host.data() + off, src, bytes);
+        return off;
+    };
+    size_t offs[MAX_LEVELS][8];
+    for (int k = 0; k <= levels; ++k) {
+        LevelGeom &g = pl->lv[k];
+        double scale = 1;
+        for (int i = 0; i < k; ++i) scale *= pyr_scale;
+        const double sigma = (1. / scale - 1) * 0.5;
+        int sz = cv_round(sigma * 5) | 1;
+        g.ksize = sz > 3 ? sz : 3;
+        g.lw = cv_round(W * scale);
+        g.lh = cv_round(H * scale);
+        if (g.ksize > MAX_KS) { delete pl; ipx_set_error("Gaussian aperture %d unsupported", g.ksize); return IPX_ERR_UNSUPPORTED; }
+        gaussian_kernel(g.ksize, sigma, g.kern);
+        g.mode = (g.lw == W && g.lh == H) ? 0 : (W == 2 * g.lw && H == 2 * g.lh) ? 1 : 2;
+        std::vector<int> xo, yo; std::vector<float> xa, yb;
+        linear_table_x(W, g.lw, xo, xa);
+        linear_table_y(H, g.lh, yo, yb);
+        offs[k][0] = push(xo.data(), xo.size() * 4); offs[k][1] = push(xa.data(), xa.size() * 4);
+        offs[k][2] = push(yo.data(), yo.size() * 4); offs[k][3] = push(yb.data(), yb.size() * 4);
+    }
+    for (int k = 0; k < levels; ++k) {                       // flow of level k from level k+1
+        std::vector<int> xo, yo; std::vector<float> xa, yb;
+        linear_table_x(pl->lv[k + 1].lw, pl->lv[k].lw, xo, xa);
+        linear_table_y(pl->lv[k + 1].lh, pl->lv[k].lh, yo, yb);
+        offs[k][4] = push(xo.data(), xo.size() * 4); offs[k][5] = push(xa.data(), xa.size() * 4);
+        offs[k][6] = push(yo.data(), yo.size() * 4); offs[k][7] = push(yb.data(), yb.size() * 4);
+    }
+    void *dev;
+    int e = ipx_scratch(ctx, SLOT_FLOW_TAB, host.size(), &dev);
+    if (e) { delete pl; return e; }
+    hipError_t he = hipMemcpyAsync(dev, host.data(), host.size(), hipMemcpyHostToDevice, ctx->stream);
+    if (he == hipSuccess) he = hipStreamSynchronize(ctx->stream);   // `host` dies at return
+    if (he != hipSuccess) { delete pl; ipx_set_error("table upload failed: %s", hipGetErrorString(he)); return IPX_ERR_HIP; }
+    const char *d = (const char *)dev;
+    for (int k = 0; k <= levels; ++k) {
+        LevelGeom &g = pl->lv[k];
+        g.x_ofs = (const int *)(d + offs[k][0]); g.x_a = (const float *)(d + offs[k][1]);
+        g.y_ofs = (const int *)(d + offs[k][2]); g.y_b = (const float *)(d + offs[k][3]);
+        if (k < levels) {
+            g.ux_ofs = (const int *)(d + offs[k][4]); g.ux_a = (const float *)(d + offs[k][5]);
+            g.uy_ofs = (const int *)(d + offs[k][6]); g.uy_b = (const float *)(d + offs[k][7]);
+        }
+    }
+    ctx->flow_plan = pl;
+    return IPX_OK;
+}
+
+inline dim3 grid64x4(int w, int h, int z) { return dim3((w + 63) / 64, (h + 3) / 4, z); }
+
+// Level image + polynomial expansion of launch frames [0, nf) (chunk frames first..first+nf-1).
+int launch_level_expansion(ipx_ctx *ctx, const LevelGeom &g, const uint8_t *frames, const uint8_t *extra, int first,
+                           int nf, float *I, float *R)
+{
+    const ipx_flow_plan *pl = ctx->flow_plan;
+    PyrArgs a;
+    a.frames = frames; a.extra = extra; a.first = first; a.H = pl->H; a.W = pl->W; a.lh = g.lh; a.lw = g.lw;
+    a.mode = g.mode; a.x_ofs = g.x_ofs; a.x_a = g.x_a; a.y_ofs = g.y_ofs; a.y_b = g.y_b; a.out = I;
+    memcpy(a.kt.k, g.kern, sizeof(a.kt.k));
+    const dim3 grid = grid64x4(g.lw, g.lh, nf), block(256);
+    switch (g.ksize) {
+    case 3: hipLaunchKernelGGL(pyr_level_kernel<3>, grid, block, 0, ctx->stream, a); break;
+    case 9: hipLaunchKernelGGL(pyr_level_kernel<9>, grid, block, 0, ctx->stream, a); break;
+    case 19: hipLaunchKernelGGL(pyr_level_kernel<19>, grid, block, 0, ctx->stream, a); break;
+    default:
+        ipx_set_error("Gaussian aperture %d unsupported", g.ksize);
+        return IPX_ERR_UNSUPPORTED;
+    }
+    hipLaunchKernelGGL(polyexp_kernel, dim3((g.lw + PX_TW - 1) / PX_TW, (g.lh + PX_TH - 1) / PX_TH, nf), block, 0,
+                       ctx->stream, I, g.lh, g.lw, pl->pc, R);
+    IPX_LAUNCH_CHECK();
+    return IPX_OK;
+}
+
+// Flow fields of `np` pairs; pair p = launch frames (p, p+1).  Result: level-0 flow in uv_out.
+int run_pairs(ipx_ctx *ctx, const uint8_t *frames, const uint8_t *extra, int first, int np, float2 **uv_out)
+{
+    const ipx_flow_plan *pl = ctx->flow_plan;
+    const int nf = np + 1;
+    const size_t P0 = (size_t)pl->lv[0].lh * pl->lv[0].lw;
+    void *pyr, *mat, *uv;
+    IPX_TRY(ipx_scratch(ctx, SLOT_FLOW_PYR, (size_t)nf * P0 * 6 * sizeof(float), &pyr));
+    IPX_TRY(ipx_scratch(ctx, SLOT_FLOW_MAT, (size_t)np * P0 * 5 * sizeof(float), &mat));
+    const size_t P1 = pl->levels > 0 ? (size_t)pl->lv[1].lh * pl->lv[1].lw : 0;
+    IPX_TRY(ipx_scratch(ctx, SLOT_FLOW_UV, (size_t)np * (P0 + P1) * sizeof(float2) + 256, &uv));
+    float2 *uvA = (float2 *)uv;                                   // holds levels 0, 2, ...
+    float2 *uvB = uvA + ipx_align_up((size_t)np * P0, 32);       // holds levels 1, 3, ...
+    float2 *prev = nullptr;
+    const dim3 block(256);
+    for (int k = pl->levels; k >= 0; --k) {
+        const LevelGeom &g = pl->lv[k];
+        const size_t P = (size_t)g.lh * g.lw;
+        float *I = (float *)pyr, *R = I + ipx_align_up((size_t)nf * P, 64);
+        float *M = (float *)mat;
+        float2 *cur = (k & 1) ? uvB : uvA;
+        IPX_TRY(launch_level_expansion(ctx, g, frames, extra, first, nf, I, R));
+        if (!prev) {
+            IPX_CHECK_HIP(hipMemsetAsync(cur, 0, (size_t)np * P * sizeof(float2), ctx->stream));
+        } else {
+            const LevelGeom &c = pl->lv[k + 1];
+            hipLaunchKernelGGL(flow_upsample_kernel, grid64x4(g.lw, g.lh, np), block, 0, ctx->stream, prev, c.lh, c.lw,
+                               cur, g.lh, g.lw, g.ux_ofs, g.ux_a, g.uy_ofs, g.uy_b);
+        }
+        hipLaunchKernelGGL(update_matrices_kernel, grid64x4(g.lw, g.lh, np), block, 0, ctx->stream, R, cur, g.lh, g.lw, M);
+        const dim3 bgrid((g.lw + BS_TW - 1) / BS_TW, (g.lh + BS_TH - 1) / BS_TH, np);
+        for (int it = 0; it < 3; ++it) {                            // ip.py:864 iterations=3
+            hipLaunchKernelGGL(blur_solve_kernel, bgrid, block, 0, ctx->stream, M, g.lh, g.lw, cur);
+            if (it < 2)
+                hipLaunchKernelGGL(update_matrices_kernel, grid64x4(g.lw, g.lh, np), block, 0, ctx->stream, R, cur, g.lh, g.lw, M);
+        }
+        IPX_LAUNCH_CHECK();
+        prev = cur;
+    }
+    *uv_out = prev;
+    return IPX_OK;
+}
+
+// pairs per batch: bounded by a scratch budget and by grid.z
+int pair_batch(int H, int W, int want)
+{
+    const size_t per_pair = (size_t)H * W * (6 + 5 + 3) * sizeof(float);
+    size_t b = ((size_t)6 << 30) / per_pair;
+    if (b < 1) b = 1;
+    if (b > 64) b = 64;
+    if (b > (size_t)want) b = want;
+    return (int)b;
+}
+
+}  // namespace
+
+extern "C" int ipx_flow_metric(ipx_ctx *ctx, const uint8_t *frames, int n, int H, int W,
+                               const uint8_t *prev_frame, float *flows, uint8_t *keep)
+{
+    IPX_REQUIRE(ctx && frames && flows, "null pointer");
+    IPX_REQUIRE(n > 0 && H >= 2 && W >= 2, "bad sizes (frames must be at least 2x2)");
+    IPX_TRY(ipx_ctx_enter(ctx));
+    IPX_TRY(build_plan(ctx, H, W));
+    const size_t P = (size_t)H * W;
+    const int first_pair = prev_frame ? 0 : 1;       // pair i = (frame i-1, frame i)
+    if (!prev_frame) hipLaunchKernelGGL(first_frame_kernel, dim3(1), dim3(1), 0, ctx->stream, flows, keep);
+    const int total = n - first_pair;
+    if (total <= 0) { IPX_LAUNCH_CHECK(); return IPX_OK; }
+    const int B = pair_batch(H, W, total);
+    void *red;
+    IPX_TRY(ipx_scratch(ctx, SLOT_FLOW_RED, (size_t)B * RED_BLOCKS * sizeof(double), &red));
+    for (int i0 = first_pair; i0 < n; i0 += B) {
+        const int np = n - i0 < B ? n - i0 : B;
+        float2 *uv;
+        IPX_TRY(run_pairs(ctx, frames, prev_frame, i0 - 1, np, &uv));
+        hipLaunchKernelGGL(magnitude_partial_kernel, dim3(RED_BLOCKS, np), dim3(256), 0, ctx->stream, uv, P, (double *)red);
+        hipLaunchKernelGGL(magnitude_finish_kernel, dim3((np + 63) / 64), dim3(64), 0, ctx->stream, (const double *)red, P, np,
+                           ctx->p.flow_threshold, flows + i0, keep ? keep + i0 : nullptr);
+        IPX_LAUNCH_CHECK();
+    }
+    return IPX_OK;
+}
+
+namespace {
+__global__ void f32_to_u8_kernel(const float *src, size_t n, uint8_t *dst, int *bad)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float v = src[i];
+    const int q = (int)v;
+    if (!(v >= 0.f && v <= 255.f) || (float)q != v) atomicOr(bad, 1);
+    dst[i] = (uint8_t)q;
+}
+}  // namespace
+
+// Unit-parity entry point: the reference hands cv2 float32 copies of uint8 frames (ip.py:856-857),
+// so the images must hold integers in [0,255]; anything else is rejected rather than rounded.
+extern "C" int ipx_farneback_pair(ipx_ctx *ctx, const float *prev, const float *next, int H, int W, float *flow)
+{
+    IPX_REQUIRE(ctx && prev && next && flow, "null pointer");
+    IPX_REQUIRE(H >= 2 && W >= 2, "bad sizes (frames must be at least 2x2)");
+    IPX_TRY(ipx_ctx_enter(ctx));
+    IPX_TRY(build_plan(ctx, H, W));
+    const size_t P = (size_t)H * W;
+    void *st;
+    IPX_TRY(ipx_scratch(ctx, SLOT_STAGE, 2 * P + 256, &st));
+    uint8_t *u8 = (uint8_t *)st;
+    int *bad = (int *)(u8 + ipx_align_up(2 * P, 16));
+    IPX_CHECK_HIP(hipMemsetAsync(bad, 0, sizeof(int), ctx->stream));
+    const dim3 grid((unsigned)((P + 255) / 256)), block(256);
+    hipLaunchKernelGGL(f32_to_u8_kernel, grid, block, 0, ctx->stream, prev, P, u8, bad);
+    hipLaunchKernelGGL(f32_to_u8_kernel, grid, block, 0, ctx->stream, next, P, u8 + P, bad);
+    IPX_LAUNCH_CHECK();
+    int hbad = 0;
+    IPX_CHECK_HIP(hipMemcpyAsync(&hbad, bad, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    IPX_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+    if (hbad) {
+        ipx_set_error("ipx_farneback_pair: images must hold integer values in [0,255] (float copies of uint8 frames)");
+        return IPX_ERR_UNSUPPORTED;
+    }
+    float2 *uv;
+    IPX_TRY(run_pairs(ctx, u8, nullptr, 0, 1, &uv));
+    IPX_CHECK_HIP(hipMemcpyAsync(flow, uv, P * sizeof(float2), hipMemcpyDeviceToDevice, ctx->stream));
+    return IPX_OK;
+}

@@ -1,0 +1,79 @@
+// Internal declarations shared by the HIP translation units of libipx.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+#include <stdio.h>
+#include "../../include/ipx.h"
+
+// Scratch arenas of a context.  Each slot is an independent growable device buffer; a stage
+// only touches the slots listed next to it, so the chunk orchestrator can keep its planes in
+// the WS_* slots while the stages it calls reuse theirs.
+enum ipx_slot {
+    SLOT_CCL = 0,        // ccl.hip: parent/aux arrays + one plane per batched frame
+    SLOT_STAGE,          // single-stage entry points (ipx_background's dummy plane, ...)
+    SLOT_FLOW_TAB,       // flow.hip: per-(H,W) resize / filter tables
+    SLOT_FLOW_PYR,       // flow.hip: level images + polynomial expansions of a batch
+    SLOT_FLOW_MAT,       // flow.hip: G/h matrices of a batch
+    SLOT_FLOW_UV,        // flow.hip: flow fields (two levels, ping-pong)
+    SLOT_FLOW_RED,       // flow.hip: partial sums of the magnitude reduction
+    WS_RAW, WS_BRIGHT, WS_PERS, WS_STATIC, WS_FINAL, WS_MAPS, WS_COUNTS,   // chunk.hip
+    SLOT_COUNT
+};
+
+struct ipx_flow_plan;   // flow.hip
+
+struct ipx_ctx {
+    int device;
+    hipStream_t stream;
+    ipx_params p;
+    void *slot[SLOT_COUNT];
+    size_t slot_bytes[SLOT_COUNT];
+    hipEvent_t ev0, ev1;
+    ipx_flow_plan *flow_plan;   // cached tables for the last (H,W) seen by the flow stage
+};
+
+void ipx_set_error(const char *fmt, ...);
+
+#define IPX_CHECK_HIP(expr)                                                            \
+    do {                                                                               \
+        hipError_t _e = (expr);                                                        \
+        if (_e != hipSuccess) {                                                        \
+            ipx_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e),       \
+                          __FILE__, __LINE__);                                         \
+            return IPX_ERR_HIP;                                                        \
+        }                                                                              \
+    } while (0)
+
+#define IPX_REQUIRE(cond, msg)                                                         \
+    do {                                                                               \
+        if (!(cond)) {                                                                 \
+            ipx_set_error("%s: %s", __func__, msg);                                    \
+            return IPX_ERR_ARG;                                                        \
+        }                                                                              \
+    } while (0)
+
+#define IPX_TRY(expr)                                                                  \
+    do {                                                                               \
+        int _s = (expr);                                                               \
+        if (_s != IPX_OK) return _s;                                                   \
+    } while (0)
+
+#define IPX_LAUNCH_CHECK() IPX_CHECK_HIP(hipGetLastError())
+
+// Makes ctx->device current.
+int ipx_ctx_enter(ipx_ctx *ctx);
+// Grows slot `s` to at least `bytes` (synchronises the stream before freeing the old arena).
+int ipx_scratch(ipx_ctx *ctx, int s, size_t bytes, void **out);
+void ipx_flow_plan_free(ipx_flow_plan *plan);
+
+static inline int ipx_wpr(int W) { return (W + 63) >> 6; }
+static inline size_t ipx_align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// Thresholds derived from ipx_params the way numpy compares (see include/ipx.h).
+struct ipx_derived {
+    int frame_gt;        // frame > brightness_threshold  <=>  (int)frame > frame_gt
+    float bg_gt;         // background(f32) > (float)brightness_threshold
+    int est_lt;          // frame < estimate_threshold
+};
+ipx_derived ipx_derive(const ipx_params &p);

@@ -1,0 +1,255 @@
+// temporal.hip -- chunk-global temporal maps and the per-frame integer counters (gfx950).
+//
+//   compute_persistent_mask    ip.py:270-289   longest run of consecutive flagged frames >= T
+//   filter_consecutive_pixels  ip.py:292-310   clean = raw & ~persistent
+//   compute_static_mask        ip.py:438-465   heat / valid percentage map > static_threshold
+//   apply_static_suppression   ip.py:468-481   final = clean & ~(persistent | static)
+//   estimate_... / find_bright_area_estimates / _get_final_count  ip.py:770-847, 351-365
+//     (their per-frame integer counters; the float glue stays on the host)
+//
+// All masks are packed bit-planes; a lane owns one 64-pixel word and streams the n planes.
+#include "ipx_internal.h"
+
+namespace {
+
+// Bit-sliced saturating run-length counters: K planes of 64 lanes each.
+template <int K>
+__global__ void persistent_kernel(const uint64_t *raw, const uint8_t *keep, int n, size_t words, int T,
+                                  uint64_t valid_unused, uint64_t *out)
+{
+    const size_t w = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= words) return;
+    uint64_t c[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) c[k] = 0;
+    uint64_t pers = 0;
+    for (int i = 0; i < n; ++i) {
+        const uint64_t m = (keep == nullptr || keep[i]) ? raw[(size_t)i * words + w] : 0ull;   // None resets runs
+        // cnt = m ? min(cnt + 1, 2^K - 1) : 0
+        uint64_t carry = m;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const uint64_t t = c[k] & carry;
+            c[k] ^= carry;
+            carry = t;
+        }
+#pragma unroll
+        for (int k = 0; k < K; ++k) c[k] = (c[k] | carry) & m;     // saturate on overflow, reset where m = 0
+        // ge = cnt >= T, MSB-first comparison against the constant T
+        uint64_t gt = 0, eq = ~0ull;
+#pragma unroll
+        for (int k = K - 1; k >= 0; --k) {
+            if ((T >> k) & 1) eq &= c[k];
+            else { gt |= eq & c[k]; eq &= ~c[k]; }
+        }
+        pers |= gt | eq;
+    }
+    out[w] = pers;
+}
+
+__global__ void fill_plane_kernel(uint64_t *out, int H, int W, int wpr)
+{
+    const size_t w = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= (size_t)H * wpr) return;
+    const int k = (int)(w % wpr);
+    const int valid = W - 64 * k;
+    out[w] = valid >= 64 ? ~0ull : (1ull << valid) - 1;
+}
+
+// heat = sum clean, valid = sum !(frame > bt & !clean); one lane owns 4 consecutive pixels.
+__global__ void static_maps_kernel(const uint8_t *frames, const uint64_t *raw, const uint64_t *pers,
+                                   const uint8_t *keep, int n, int H, int W, int wpr, int frame_gt,
+                                   int32_t *heat, int32_t *valid)
+{
+    const int xq = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    const int y = blockIdx.y;
+    if (xq >= W) return;
+    const size_t words = (size_t)H * wpr;
+    const size_t wi = (size_t)y * wpr + (xq >> 6);
+    const int sh = xq & 63;
+    const uint64_t notp = ~pers[wi];
+    const bool aligned = (W & 3) == 0;
+    const size_t P = (size_t)H * W;
+    const uint8_t *px = frames + (size_t)y * W + xq;
+    int hc[4] = {0, 0, 0, 0}, vc[4] = {0, 0, 0, 0};
+    for (int i = 0; i < n; ++i) {
+        uint32_t f;
+        if (aligned) f = *reinterpret_cast<const uint32_t *>(px + (size_t)i * P);
+        else {
+            f = 0;
+            for (int j = 0; j < 4; ++j)
+                if (xq + j < W) f |= (uint32_t)px[(size_t)i * P + j] << (8 * j);
+        }
+        const uint32_t m = (keep == nullptr || keep[i]) ? (uint32_t)((raw[(size_t)i * words + wi] & notp) >> sh) & 0xf : 0u;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int mj = (m >> j) & 1;
+            const int bright = ((int)((f >> (8 * j)) & 0xff) > frame_gt) & (mj ^ 1);
+            hc[j] += mj;
+            vc[j] += bright ^ 1;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        if (xq + j < W) {
+            heat[(size_t)y * W + xq + j] = hc[j];
+            valid[(size_t)y * W + xq + j] = vc[j];
+        }
+}
+
+__global__ void or_planes_kernel(const uint64_t *planes, int count, size_t words, uint64_t *out)
+{
+    const size_t w = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= words) return;
+    uint64_t r = 0;
+    for (int i = 0; i < count; ++i) r |= planes[(size_t)i * words + w];
+    out[w] = r;
+}
+
+// percentage_map > static_threshold where valid > min_valid_frames, ip.py:461-465 (float64)
+__global__ void static_from_maps_kernel(const int32_t *heat, const int32_t *valid, int H, int W, int wpr,
+                                        int min_valid, double thr, uint64_t *out)
+{
+    const int lane = threadIdx.x & 63;
+    const size_t word = (size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (word >= (size_t)H * wpr) return;
+    const size_t y = word / wpr;
+    const int x = (int)(word - y * wpr) * 64 + lane;
+    bool on = false;
+    if (x < W) {
+        const int v = valid[y * W + x];
+        if (v > min_valid) {
+            double pct = (double)heat[y * W + x] / (double)v;
+            pct = pct * 100.0;
+            on = pct > thr;
+        }
+    }
+    const unsigned long long b = __ballot(on);
+    if (lane == 0) out[word] = b;
+}
+
+// final planes + per-frame counters {sum(final), #(final & f < est_lt), #(final & f > frame_gt)}
+__global__ void finalize_kernel(const uint8_t *frames, const uint64_t *raw, const uint64_t *pers,
+                                const uint64_t *stat, const uint8_t *keep, int H, int W, int wpr,
+                                int est_lt, int frame_gt, uint64_t *fin, unsigned long long *counts)
+{
+    const size_t words = (size_t)H * wpr;
+    const int i = blockIdx.y;
+    const size_t w = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned c0 = 0, c1 = 0, c2 = 0;
+    if (w < words) {
+        uint64_t m = 0;
+        if (keep == nullptr || keep[i]) m = raw[(size_t)i * words + w] & ~(pers[w] | (stat ? stat[w] : 0ull));
+        if (fin) fin[(size_t)i * words + w] = m;
+        if (m) {
+            c0 = __builtin_popcountll(m);
+            const size_t y = w / wpr;
+            const uint8_t *row = frames + ((size_t)i * H + y) * W + (w - y * wpr) * 64;
+            uint64_t rem = m;
+            while (rem) {
+                const int b = __builtin_ctzll(rem);
+                rem &= rem - 1;
+                const int f = row[b];
+                c1 += f < est_lt;
+                c2 += f > frame_gt;
+            }
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        c0 += __shfl_down(c0, off);
+        c1 += __shfl_down(c1, off);
+        c2 += __shfl_down(c2, off);
+    }
+    if ((threadIdx.x & 63) == 0 && (c0 | c1 | c2)) {
+        atomicAdd(counts + (size_t)i * 3 + 0, (unsigned long long)c0);
+        atomicAdd(counts + (size_t)i * 3 + 1, (unsigned long long)c1);
+        atomicAdd(counts + (size_t)i * 3 + 2, (unsigned long long)c2);
+    }
+}
+
+}  // namespace
+
+extern "C" int ipx_persistent_mask(ipx_ctx *ctx, const uint64_t *raw_bits, const uint8_t *keep, int n, int H, int W,
+                                   uint64_t *persistent_bits)
+{
+    IPX_REQUIRE(ctx && raw_bits && persistent_bits, "null pointer");
+    IPX_REQUIRE(n > 0 && H > 0 && W > 0, "bad sizes");
+    if (int e = ipx_ctx_enter(ctx)) return e;
+    const int wpr = ipx_wpr(W);
+    const size_t words = (size_t)H * wpr;
+    const dim3 grid((unsigned)((words + 255) / 256)), block(256);
+    const int T = ctx->p.consecutive_threshold;
+    if (T <= 0) {                     // longest >= T holds for every pixel, ip.py:289
+        hipLaunchKernelGGL(fill_plane_kernel, grid, block, 0, ctx->stream, persistent_bits, H, W, wpr);
+    } else if (T > n) {               // no run can be that long
+        IPX_CHECK_HIP(hipMemsetAsync(persistent_bits, 0, words * 8, ctx->stream));
+    } else if (T < 4) {
+        hipLaunchKernelGGL(persistent_kernel<2>, grid, block, 0, ctx->stream, raw_bits, keep, n, words, T, 0ull, persistent_bits);
+    } else if (T < 256) {
+        hipLaunchKernelGGL(persistent_kernel<8>, grid, block, 0, ctx->stream, raw_bits, keep, n, words, T, 0ull, persistent_bits);
+    } else {
+        hipLaunchKernelGGL(persistent_kernel<24>, grid, block, 0, ctx->stream, raw_bits, keep, n, words, T, 0ull, persistent_bits);
+    }
+    IPX_LAUNCH_CHECK();
+    return IPX_OK;
+}
+
+extern "C" int ipx_static_maps(ipx_ctx *ctx, const uint8_t *frames, const uint64_t *raw_bits,
+                               const uint64_t *persistent_bits, const uint8_t *keep, int n, int H, int W,
+                               int32_t *heat, int32_t *valid)
+{
+    IPX_REQUIRE(ctx && frames && raw_bits && persistent_bits && heat && valid, "null pointer");
+    IPX_REQUIRE(n > 0 && H > 0 && W > 0, "bad sizes");
+    if (int e = ipx_ctx_enter(ctx)) return e;
+    const ipx_derived d = ipx_derive(ctx->p);
+    const int quads = (W + 3) / 4;
+    const dim3 grid((quads + 63) / 64, H), block(64);
+    hipLaunchKernelGGL(static_maps_kernel, grid, block, 0, ctx->stream, frames, raw_bits, persistent_bits, keep,
+                       n, H, W, ipx_wpr(W), d.frame_gt, heat, valid);
+    IPX_LAUNCH_CHECK();
+    return IPX_OK;
+}
+
+extern "C" int ipx_static_from_maps(ipx_ctx *ctx, const int32_t *heat, const int32_t *valid, int H, int W,
+                                    uint64_t *static_bits)
+{
+    IPX_REQUIRE(ctx && heat && valid && static_bits, "null pointer");
+    IPX_REQUIRE(H > 0 && W > 0, "bad sizes");
+    if (int e = ipx_ctx_enter(ctx)) return e;
+    const int wpr = ipx_wpr(W);
+    const size_t words = (size_t)H * wpr;
+    hipLaunchKernelGGL(static_from_maps_kernel, dim3((unsigned)((words + 3) / 4)), dim3(256), 0, ctx->stream,
+                       heat, valid, H, W, wpr, ctx->p.min_valid_frames, ctx->p.static_threshold, static_bits);
+    IPX_LAUNCH_CHECK();
+    return IPX_OK;
+}
+
+extern "C" int ipx_finalize(ipx_ctx *ctx, const uint8_t *frames, const uint64_t *raw_bits,
+                            const uint64_t *persistent_bits, const uint64_t *static_bits, const uint8_t *keep,
+                            int n, int H, int W, uint64_t *final_bits, int64_t *counts)
+{
+    IPX_REQUIRE(ctx && frames && raw_bits && persistent_bits && counts, "null pointer");
+    IPX_REQUIRE(n > 0 && n <= 65535 && H > 0 && W > 0, "bad sizes (n <= 65535 frames per call)");
+    if (int e = ipx_ctx_enter(ctx)) return e;
+    const ipx_derived d = ipx_derive(ctx->p);
+    const int wpr = ipx_wpr(W);
+    const size_t words = (size_t)H * wpr;
+    IPX_CHECK_HIP(hipMemsetAsync(counts, 0, sizeof(int64_t) * 3 * (size_t)n, ctx->stream));
+    const dim3 grid((unsigned)((words + 255) / 256), n), block(256);
+    hipLaunchKernelGGL(finalize_kernel, grid, block, 0, ctx->stream, frames, raw_bits, persistent_bits, static_bits,
+                       keep, H, W, wpr, d.est_lt, d.frame_gt, final_bits, (unsigned long long *)counts);
+    IPX_LAUNCH_CHECK();
+    return IPX_OK;
+}
+
+extern "C" int ipx_or_planes(ipx_ctx *ctx, const uint64_t *planes, int count, int H, int W, uint64_t *out)
+{
+    IPX_REQUIRE(ctx && planes && out, "null pointer");
+    IPX_REQUIRE(count > 0 && H > 0 && W > 0, "bad sizes");
+    if (int e = ipx_ctx_enter(ctx)) return e;
+    const size_t words = (size_t)H * ipx_wpr(W);
+    hipLaunchKernelGGL(or_planes_kernel, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, ctx->stream, planes, count,
+                       words, out);
+    IPX_LAUNCH_CHECK();
+    return IPX_OK;
+}

@@ -1,0 +1,248 @@
+"""Engine: one libipx context on one MI355X, with torch supplying device memory and streams.
+
+torch is plumbing here (allocation, H2D/D2H copies, the current HIP stream, torch.distributed);
+every computation is a libipx call through the C ABI of include/ipx.h.  Tensors handed to the
+methods must live on the engine's device; ``to_device`` uploads numpy arrays.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _ipx
+from . import hostmath
+
+lib = _ipx.lib
+check = _ipx.check
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+class Engine:
+    def __init__(self, device=0, params=None):
+        if not torch.cuda.is_available():
+            raise RuntimeError("image_processing_amd needs a ROCm GPU (MI355X); there is no CPU fallback")
+        self.device = torch.device("cuda", int(device))
+        self._ctx = C.c_void_p()
+        check(lib.ipx_ctx_create(int(device), C.byref(self._ctx)))
+        self.params = _ipx.default_params()
+        self._pow2 = None
+        self._pow2_dim = 0
+        self.set_params(params)
+
+    def close(self):
+        if self._ctx:
+            lib.ipx_ctx_destroy(self._ctx)
+            self._ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- settings (ip.py:154-180) ---------------------------------------------------------------
+    def set_params(self, params=None):
+        """``params``: dict with the reference's setting names (ip.py:167-177); missing keys keep
+        the reference defaults.  Extra keys: min_valid_frames, circularity_size_threshold,
+        estimate_threshold, pixel_std_coeff (constants the reference hard-codes)."""
+        p = _ipx.default_params()
+        d = dict(params or {})
+        d.pop("number_of_plots", None)
+        for k, v in d.items():
+            if not hasattr(p, k):
+                raise KeyError("unknown setting %r" % (k,))
+            setattr(p, k, v)
+        self.params = p
+        check(lib.ipx_set_params(self._ctx, C.byref(p)))
+        tab, dim = hostmath.pow2_table(p.max_cluster_size)
+        self._pow2 = torch.from_numpy(tab).to(self.device)
+        self._pow2_dim = dim
+
+    # ---- plumbing --------------------------------------------------------------------------------
+    def _enter(self):
+        check(lib.ipx_set_stream(self._ctx, C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)))
+
+    def synchronize(self):
+        check(lib.ipx_synchronize(self._ctx))
+
+    def to_device(self, a, dtype=None):
+        t = torch.from_numpy(np.ascontiguousarray(a, dtype=dtype))
+        return t.to(self.device, non_blocking=False)
+
+    def _chk_frames(self, frames):
+        assert frames.is_cuda and frames.device == self.device and frames.dtype == torch.uint8
+        assert frames.dim() == 3 and frames.is_contiguous()
+        return frames.shape
+
+    def wpr(self, W):
+        return (W + 63) // 64
+
+    def empty_bits(self, count, H, W):
+        return torch.empty((count, H, self.wpr(W)), dtype=torch.int64, device=self.device)
+
+    def timer_begin(self):
+        self._enter()
+        check(lib.ipx_timer_begin(self._ctx))
+
+    def timer_end(self):
+        ms = C.c_float()
+        check(lib.ipx_timer_end(self._ctx, C.byref(ms)))
+        return ms.value
+
+    # ---- stages on device tensors ------------------------------------------------------------------
+    def bgr2gray(self, bgr):
+        assert bgr.dtype == torch.uint8 and bgr.is_contiguous() and bgr.shape[-1] == 3
+        gray = torch.empty(bgr.shape[:-1], dtype=torch.uint8, device=self.device)
+        self._enter()
+        check(lib.ipx_bgr2gray(self._ctx, _ptr(bgr), gray.numel(), _ptr(gray)))
+        return gray
+
+    def flow_metric(self, frames, prev_frame=None, want_keep=True):
+        n, H, W = self._chk_frames(frames)
+        flows = torch.empty(n, dtype=torch.float32, device=self.device)
+        keep = torch.empty(n, dtype=torch.uint8, device=self.device) if want_keep else None
+        self._enter()
+        check(lib.ipx_flow_metric(self._ctx, _ptr(frames), n, H, W, _ptr(prev_frame), _ptr(flows), _ptr(keep)))
+        return flows, keep
+
+    def farneback_pair(self, prev, nxt):
+        H, W = prev.shape
+        flow = torch.empty((H, W, 2), dtype=torch.float32, device=self.device)
+        self._enter()
+        check(lib.ipx_farneback_pair(self._ctx, _ptr(prev), _ptr(nxt), H, W, _ptr(flow)))
+        return flow
+
+    def background(self, frames, index):
+        n, H, W = self._chk_frames(frames)
+        bg = torch.empty((H, W), dtype=torch.float32, device=self.device)
+        self._enter()
+        check(lib.ipx_background(self._ctx, _ptr(frames), n, H, W, int(index), _ptr(bg)))
+        return bg
+
+    def damaged_mask(self, frame, bg):
+        H, W = frame.shape
+        assert frame.dtype == torch.uint8 and bg.shape == frame.shape
+        f64 = bg.dtype == torch.float64
+        assert f64 or bg.dtype == torch.float32
+        mask = torch.empty((H, W), dtype=torch.uint8, device=self.device)
+        thr = torch.empty_like(bg)
+        self._enter()
+        check(lib.ipx_damaged_mask(self._ctx, _ptr(frame), H, W, _ptr(bg), int(f64), _ptr(mask), _ptr(thr)))
+        return mask, thr
+
+    def detect_raw(self, frames, keep=None, first=0, count=None, want_dense=True, raw_out=None):
+        n, H, W = self._chk_frames(frames)
+        count = n - first if count is None else count
+        raw = self.empty_bits(count, H, W) if raw_out is None else raw_out
+        bright = self.empty_bits(count, H, W)
+        dense = torch.empty((count, 2), dtype=torch.int64, device=self.device) if want_dense else None
+        self._enter()
+        check(lib.ipx_detect_raw(self._ctx, _ptr(frames), n, H, W, first, count, _ptr(keep), _ptr(raw), _ptr(bright),
+                                 _ptr(dense)))
+        return raw, bright, dense
+
+    def remove_bright_regions(self, bright_bits, damaged_bits, H, W, out=None):
+        count = damaged_bits.shape[0]
+        out = torch.empty_like(damaged_bits) if out is None else out
+        self._enter()
+        check(lib.ipx_remove_bright_regions(self._ctx, _ptr(bright_bits), _ptr(damaged_bits), count, H, W, _ptr(out)))
+        return out
+
+    def persistent_mask(self, raw_bits, keep, H, W):
+        n = raw_bits.shape[0]
+        out = self.empty_bits(1, H, W)[0]
+        self._enter()
+        check(lib.ipx_persistent_mask(self._ctx, _ptr(raw_bits), _ptr(keep), n, H, W, _ptr(out)))
+        return out
+
+    def or_planes(self, planes, H, W):
+        out = self.empty_bits(1, H, W)[0]
+        self._enter()
+        check(lib.ipx_or_planes(self._ctx, _ptr(planes), planes.shape[0], H, W, _ptr(out)))
+        return out
+
+    def static_maps(self, frames, raw_bits, pers_bits, keep):
+        n, H, W = self._chk_frames(frames)
+        maps = torch.empty((2, H, W), dtype=torch.int32, device=self.device)
+        self._enter()
+        check(lib.ipx_static_maps(self._ctx, _ptr(frames), _ptr(raw_bits), _ptr(pers_bits), _ptr(keep), n, H, W,
+                                  _ptr(maps[0]), _ptr(maps[1])))
+        return maps
+
+    def static_from_maps(self, maps):
+        _, H, W = maps.shape
+        out = self.empty_bits(1, H, W)[0]
+        self._enter()
+        check(lib.ipx_static_from_maps(self._ctx, _ptr(maps[0]), _ptr(maps[1]), H, W, _ptr(out)))
+        return out
+
+    def finalize(self, frames, raw_bits, pers_bits, static_bits, keep, want_bits=True):
+        n, H, W = self._chk_frames(frames)
+        fin = self.empty_bits(n, H, W) if want_bits else None
+        counts = torch.empty((n, 3), dtype=torch.int64, device=self.device)
+        self._enter()
+        check(lib.ipx_finalize(self._ctx, _ptr(frames), _ptr(raw_bits), _ptr(pers_bits), _ptr(static_bits), _ptr(keep),
+                               n, H, W, _ptr(fin), _ptr(counts)))
+        return fin, counts
+
+    def cluster_stats(self, frames, mask_bits, keep=None, want_cleaned=False):
+        n, H, W = self._chk_frames(frames)
+        stats = torch.empty((n, 3), dtype=torch.int64, device=self.device)
+        cleaned = self.empty_bits(n, H, W) if want_cleaned else None
+        self._enter()
+        check(lib.ipx_cluster_stats(self._ctx, _ptr(frames), _ptr(mask_bits), _ptr(keep), n, H, W, _ptr(self._pow2),
+                                    self._pow2_dim, _ptr(stats), _ptr(cleaned)))
+        return stats, cleaned
+
+    def pack_mask(self, masks):
+        """(count,H,W) u8/bool device tensor -> bit-planes."""
+        count, H, W = masks.shape
+        m8 = masks.to(torch.uint8).contiguous()
+        bits = self.empty_bits(count, H, W)
+        self._enter()
+        check(lib.ipx_pack_mask(self._ctx, _ptr(m8), count, H, W, _ptr(bits)))
+        return bits
+
+    def unpack_mask(self, bits, H, W):
+        count = bits.shape[0]
+        out = torch.empty((count, H, W), dtype=torch.uint8, device=self.device)
+        self._enter()
+        check(lib.ipx_unpack_mask(self._ctx, _ptr(bits), count, H, W, _ptr(out)))
+        return out
+
+    # ---- the whole chunk (ip.py:526-632) -----------------------------------------------------------
+    def detect_chunk_device(self, frames, want_final_bits=False):
+        """Enqueue the whole path for a resident chunk; returns device tensors (no host sync)."""
+        n, H, W = self._chk_frames(frames)
+        flows = torch.empty(n, dtype=torch.float32, device=self.device)
+        keep = torch.empty(n, dtype=torch.uint8, device=self.device)
+        counts = torch.empty((n, 5), dtype=torch.int64, device=self.device)
+        cluster = torch.empty((n, 3), dtype=torch.int64, device=self.device)
+        fin = self.empty_bits(n, H, W) if want_final_bits else None
+        self._enter()
+        check(lib.ipx_detect_chunk(self._ctx, _ptr(frames), n, H, W, _ptr(self._pow2), self._pow2_dim, _ptr(flows),
+                                   _ptr(keep), _ptr(counts), _ptr(cluster), _ptr(fin)))
+        return dict(flows=flows, keep=keep, counts=counts, cluster=cluster, final_bits=fin)
+
+    def detect_chunk(self, frames, want_masks=False):
+        """frames: (n,H,W) uint8 numpy array or device tensor -> dict with the four float64 arrays
+        of ip.py:632 (``total_counts, cluster_counts, avg_sizes, avg_brightnesses``), ``flows``
+        (float32 metric as float64, ip.py:872) and ``keep``; ``final_masks`` on request."""
+        if not torch.is_tensor(frames):
+            frames = self.to_device(frames, np.uint8)
+        n, H, W = frames.shape
+        d = self.detect_chunk_device(frames, want_final_bits=want_masks)
+        keep = d["keep"].cpu().numpy()
+        counts = d["counts"].cpu().numpy()
+        cluster = d["cluster"].cpu().numpy()
+        flows = d["flows"].cpu().numpy().astype(np.float64)
+        total, cc, cs, cb = hostmath.chunk_results(keep, counts, cluster, H * W)
+        out = dict(total_counts=total, cluster_counts=cc, avg_sizes=cs, avg_brightnesses=cb, flows=flows, keep=keep,
+                   counts=counts, cluster=cluster)
+        if want_masks:
+            m = self.unpack_mask(d["final_bits"], H, W).cpu().numpy().astype(bool)
+            out["final_masks"] = [m[i] if keep[i] else None for i in range(n)]
+        return out

@@ -1,0 +1,180 @@
+/*
+ * ipx.h -- C ABI of libipx.so: the MI355X (gfx950) damaged-pixel detection path.
+ *
+ * The reference (Ben-Folkard/image_processing) has no FFI layer: its boundary is the
+ * Python module namespace `image_processing` (image_processing.py, "ip.py" below).
+ * Every entry point here names the ip.py function (file:line) whose arithmetic it
+ * replaces; image_processing.py in this repository binds them with ctypes
+ * (INTEGRATION.md shows the stub).
+ *
+ * Conventions
+ *  - extern "C", plain pointers and sizes.  Every function returns 0 on success and a
+ *    negative ipx_status on failure; ipx_last_error() returns a thread-local message.
+ *  - All data pointers are DEVICE pointers on the context's GPU unless the name ends
+ *    in _host.  Inputs/outputs are caller-owned (e.g. torch tensors); scratch memory
+ *    is owned by the context.  Work is enqueued on the context's stream
+ *    (ipx_set_stream) and is asynchronous unless stated.
+ *  - frames:   uint8  [n][H][W], rows contiguous (pitch = W).
+ *  - bit-plane: uint64 [H][wpr], wpr = ipx_words_per_row(W) = ceil(W/64); bit b of word k
+ *    of row y is pixel (x = 64k+b, y); padding bits are zero.  A stack of planes is
+ *    [n][H*wpr].
+ *  - keep:     uint8 [n]; 0 marks a DISCARDED frame (the `None` masks of ip.py:557).
+ */
+#ifndef IPX_H
+#define IPX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+/* the library is built with -fvisibility=hidden: only the declarations below are exported */
+#if defined(__GNUC__)
+#pragma GCC visibility push(default)
+#endif
+
+typedef enum ipx_status {
+    IPX_OK = 0,
+    IPX_ERR_ARG = -1,      /* bad argument (null pointer, non-positive size, ...) */
+    IPX_ERR_HIP = -2,      /* a HIP runtime call failed */
+    IPX_ERR_NOMEM = -3,    /* scratch allocation failed */
+    IPX_ERR_UNSUPPORTED = -4
+} ipx_status;
+
+/* The 9 user settings of ip.py:167-177 (number_of_plots is plot-only and omitted) plus the
+ * constants the reference hard-codes on this path. */
+typedef struct ipx_params {
+    int32_t consecutive_threshold;       /* ip.py:168, used at :289 (longest >= T)            */
+    int32_t sliding_window_radius;       /* ip.py:175, used at :189-190                        */
+    int32_t min_cluster_size;            /* ip.py:172, :678                                    */
+    int32_t max_cluster_size;            /* ip.py:173, :678 and :753 (area >= max => remove)   */
+    int32_t min_valid_frames;            /* 10, hard-coded at ip.py:589                        */
+    int32_t circularity_size_threshold;  /* 10, default at ip.py:657                           */
+    int32_t estimate_threshold;          /* 170, default at ip.py:773 (not forwarded at :836)  */
+    int32_t reserved0;
+    double brightness_threshold;         /* ip.py:169, :457 (frame > t), :743 (bg > t)         */
+    double flow_threshold;               /* ip.py:170, :559 (flow <= t keeps the frame)        */
+    double static_threshold;             /* ip.py:171, :465                                    */
+    double min_circularity;              /* ip.py:174, :701 (compared in float32)              */
+    double pixel_std_coeff;              /* 1.0, default at ip.py:204                          */
+} ipx_params;
+
+typedef struct ipx_ctx ipx_ctx;
+
+/* ---- library / context ------------------------------------------------------------------ */
+const char *ipx_last_error(void);
+int ipx_version(void);
+int ipx_device_count(int *count);
+void ipx_default_params(ipx_params *p);                         /* ip.py:167-177 defaults    */
+int ipx_words_per_row(int W);
+
+int ipx_ctx_create(int device, ipx_ctx **out);
+int ipx_ctx_destroy(ipx_ctx *ctx);
+int ipx_set_params(ipx_ctx *ctx, const ipx_params *p);          /* replaces ip.py:154-180    */
+int ipx_set_stream(ipx_ctx *ctx, void *hip_stream);             /* NULL = default stream     */
+int ipx_synchronize(ipx_ctx *ctx);
+/* Timing of the kernels enqueued between begin/end on the context's stream (HIP events). */
+int ipx_timer_begin(ipx_ctx *ctx);
+int ipx_timer_end(ipx_ctx *ctx, float *elapsed_ms);             /* synchronises               */
+
+/* ---- a1: load_video_frames' grey conversion, ip.py:78-79 (cv2.cvtColor BGR2GRAY) --------- */
+int ipx_bgr2gray(ipx_ctx *ctx, const uint8_t *bgr, size_t npix, uint8_t *gray);
+
+/* ---- a3: compute_optical_flow_metric, ip.py:852-873 --------------------------------------
+ * flows[0] = 0 (or the metric against prev_frame when given: the left halo of a frame-range
+ * shard); flows[i] = mean Farneback flow magnitude between frames i-1 and i, as float32
+ * (np.mean of an f32 array).  keep[i] = (double)flows[i] <= flow_threshold (ip.py:559). */
+int ipx_flow_metric(ipx_ctx *ctx, const uint8_t *frames, int n, int H, int W,
+                    const uint8_t *prev_frame, float *flows, uint8_t *keep);
+/* One Farneback pair on float32 images, full flow field (H,W,2) out: unit parity of
+ * cv2.calcOpticalFlowFarneback(prev,next,None,0.5,3,15,3,5,2.0,0), ip.py:858-867. */
+int ipx_farneback_pair(ipx_ctx *ctx, const float *prev, const float *next, int H, int W, float *flow);
+
+/* ---- a4/a5: compute_background + _find_background, ip.py:183-252 -------------------------- */
+int ipx_background(ipx_ctx *ctx, const uint8_t *frames, int n, int H, int W, int index, float *bg);
+
+/* ---- a6/a7: _raw_damaged_mask / get_damaged_pixel_mask, ip.py:255-267, 635-648 ------------
+ * bg_is_f64 selects the dtype the threshold chain of ip.py:638 runs in.  mask: uint8 (H,W);
+ * thr: same dtype as bg (may be NULL). */
+int ipx_damaged_mask(ipx_ctx *ctx, const uint8_t *frame, int H, int W, const void *bg,
+                     int bg_is_f64, uint8_t *mask, void *thr);
+
+/* ---- a4-a7 fused for a range of frames of a resident chunk (the hot kernel) ---------------
+ * For frames first..first+count-1 of the n-frame chunk with keep != 0: raw damaged bit-plane
+ * (ip.py:565) and bright-background bit-plane (background > brightness_threshold, ip.py:743).
+ * dense_counts (may be NULL): int64 [count][2] = { #(frame < estimate_threshold),
+ * #(frame > brightness_threshold) } per kept frame (inputs of a13/a14).
+ * Planes of discarded frames are zeroed. */
+int ipx_detect_raw(ipx_ctx *ctx, const uint8_t *frames, int n, int H, int W, int first, int count,
+                   const uint8_t *keep, uint64_t *raw_bits, uint64_t *bright_bits,
+                   int64_t *dense_counts);
+
+/* ---- a8: remove_bright_regions, ip.py:731-767, on `count` independent planes ---------------
+ * bright_bits: (background > threshold); damaged_bits in, cleaned bits out (may alias in). */
+int ipx_remove_bright_regions(ipx_ctx *ctx, const uint64_t *bright_bits, const uint64_t *damaged_bits,
+                              int count, int H, int W, uint64_t *out_bits);
+
+/* ---- a9: compute_persistent_mask, ip.py:270-289 -------------------------------------------
+ * Planes of discarded frames (keep[i] == 0, or all-zero planes when keep is NULL) reset the
+ * runs, as the `None` entries do at ip.py:281-282.  A frame-range shard calls this on
+ * [T-1 planes of the left neighbour | its own planes | T-1 planes of the right neighbour] and
+ * ORs the shards' results (ipx_or_planes): every run of >= T frames has T consecutive frames
+ * inside two adjacent shards as long as each shard holds at least T-1 frames. */
+int ipx_persistent_mask(ipx_ctx *ctx, const uint64_t *raw_bits, const uint8_t *keep, int n, int H, int W,
+                        uint64_t *persistent_bits);
+/* out = planes[0] | ... | planes[count-1]  (merge of the shards' persistence maps; no
+ * counterpart in the single-process reference).  out may alias planes[0]. */
+int ipx_or_planes(ipx_ctx *ctx, const uint64_t *planes, int count, int H, int W, uint64_t *out);
+
+/* ---- a10+a11 (first half): heat / valid maps of compute_static_mask, ip.py:451-459 ----------
+ * clean = raw & ~persistent for kept frames, zero otherwise (ip.py:306, :451).
+ * heat, valid: int32 (H,W), OVERWRITTEN with this call's n frames (sum across shards with
+ * an all-reduce before ipx_static_from_maps). */
+int ipx_static_maps(ipx_ctx *ctx, const uint8_t *frames, const uint64_t *raw_bits,
+                    const uint64_t *persistent_bits, const uint8_t *keep, int n, int H, int W,
+                    int32_t *heat, int32_t *valid);
+/* ---- a11 (second half): percentage map > static_threshold, ip.py:461-465 ------------------- */
+int ipx_static_from_maps(ipx_ctx *ctx, const int32_t *heat, const int32_t *valid, int H, int W,
+                         uint64_t *static_bits);
+
+/* ---- a10+a12+a13+a14 counters: final masks and the per-frame integer counters ---------------
+ * final = raw & ~(persistent | static) for kept frames (ip.py:306, :469-478), zero planes for
+ * discarded ones.  counts: int64 [n][3] = { sum(final), #(final & frame < estimate_threshold),
+ * #(final & frame > brightness_threshold) } (ip.py:800-805, :840). */
+int ipx_finalize(ipx_ctx *ctx, const uint8_t *frames, const uint64_t *raw_bits,
+                 const uint64_t *persistent_bits, const uint64_t *static_bits, const uint8_t *keep,
+                 int n, int H, int W, uint64_t *final_bits, int64_t *counts);
+
+/* ---- a16/a17: compute_cluster_stats / filter_damaged_pixel_clusters, ip.py:332-348, 651-728 --
+ * Per frame with keep != 0: morphological close (3x3 cross), 8-connected components, size
+ * filter, circularity filter via the outer-contour perimeter; stats: int64 [n][3] =
+ * { cluster_count, sum of kept areas, sum of frame brightness over kept components }.
+ * cleaned_bits (may be NULL): the cleaned mask of ip.py:704.
+ * pow2_table: host-built doubles [(tdim)*(tdim)], entry [a*tdim+d] = (a + d*sqrt2f)**2 as the
+ * reference's Python evaluates it (libm pow is not always p*p). */
+int ipx_cluster_stats(ipx_ctx *ctx, const uint8_t *frames, const uint64_t *mask_bits, const uint8_t *keep,
+                      int n, int H, int W, const double *pow2_table, int tdim,
+                      int64_t *stats, uint64_t *cleaned_bits);
+
+/* ---- a18: detect_damaged_pixels, ip.py:526-632, whole resident chunk -----------------------
+ * flows: float32 [n] out;  keep: uint8 [n] out;  counts: int64 [n][5] out =
+ * { sum(final), #(final&lt), #(final&gt), #(frame<estimate_threshold), #(frame>brightness_threshold) };
+ * cluster: int64 [n][3] out;  final_bits: [n][H*wpr] out (may be NULL).
+ * The host turns the integer counters into the four float64 result arrays (ip.py:605-613). */
+int ipx_detect_chunk(ipx_ctx *ctx, const uint8_t *frames, int n, int H, int W,
+                     const double *pow2_table, int tdim,
+                     float *flows, uint8_t *keep, int64_t *counts, int64_t *cluster,
+                     uint64_t *final_bits);
+
+/* ---- helpers: host<->device packing used by the Python stage wrappers ----------------------- */
+int ipx_pack_mask(ipx_ctx *ctx, const uint8_t *mask, int count, int H, int W, uint64_t *bits);
+int ipx_unpack_mask(ipx_ctx *ctx, const uint64_t *bits, int count, int H, int W, uint8_t *mask);
+
+#if defined(__GNUC__)
+#pragma GCC visibility pop
+#endif
+#ifdef __cplusplus
+}
+#endif
+#endif /* IPX_H */

@@ -1,0 +1,156 @@
+"""The motion test (Farneback flow metric) and the whole-chunk entry point vs the CPU oracle and
+the golden outputs of the reference's own orchestration.  Needs an MI355X: ``-m gpu``.
+
+Tolerances (north_star: bit-exact masks / discard lists / counts, 1e-5 relative float metrics):
+* flow field: per-pixel expressions are evaluated exactly as the oracle does; the 15x15 window
+  sums and the mean are re-associated (csrc/flow.hip), so fields agree to ~1e-5 absolute and the
+  mean magnitude to 1e-5 relative;
+* everything downstream of the discard list is compared bit-exactly.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+FLOW_RTOL = 1e-5
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from image_processing_amd.engine import Engine
+    e = Engine(0)
+    yield e
+    e.close()
+
+
+def _eq_nan(a, b):
+    return np.array_equal(np.asarray(a, float), np.asarray(b, float), equal_nan=True)
+
+
+def _moving_pair(seed, h, w, shift):
+    rng = np.random.default_rng(seed)
+    yy, xx = np.mgrid[0:h, 0:w].astype(np.float64)
+
+    def scene(off):
+        x = xx - off
+        return 90 + 50 * np.sin(x / 9.0) * np.cos(yy / 7.0) + 30 * np.sin((x + 2 * yy) / 13.0)
+    a = np.clip(np.rint(scene(0.0) + rng.normal(0, 1.5, (h, w))), 0, 255).astype(np.uint8)
+    b = np.clip(np.rint(scene(shift) + rng.normal(0, 1.5, (h, w))), 0, 255).astype(np.uint8)
+    return a, b
+
+
+# (h, w): single level; 3 exact halvings; odd sizes (general linear resize); non-multiple-of-64 widths
+@pytest.mark.parametrize("shape,shift", [((40, 56), 1.0), ((264, 360), 3.0), ((131, 203), 0.7), ((270, 480), 6.0),
+                                         ((67, 300), 2.0)])
+def test_farneback_pair_field(eng, shape, shift):
+    from oracle import cref
+    h, w = shape
+    a, b = _moving_pair(h + w, h, w, shift)
+    ref = cref.farneback(a.astype(np.float32), b.astype(np.float32))
+    got = eng.farneback_pair(eng.to_device(a.astype(np.float32)), eng.to_device(b.astype(np.float32))).cpu().numpy()
+    assert got.shape == ref.shape and np.isfinite(got).all()
+    err = np.abs(got.astype(np.float64) - ref.astype(np.float64))
+    scale = max(1.0, float(np.abs(ref).max()))
+    assert err.max() <= 2e-4 * scale, "max |dflow| = %g (flow scale %g)" % (err.max(), scale)
+    mref = float(np.mean(cref.flow_magnitude(ref)))
+    mgot = float(np.mean(cref.flow_magnitude(got)))
+    assert abs(mgot - mref) <= FLOW_RTOL * max(mref, 1e-30)
+
+
+def test_farneback_rejects_non_u8_images(eng):
+    from image_processing_amd._ipx import IpxError
+    a = np.full((40, 40), 10.5, np.float32)
+    with pytest.raises(IpxError):
+        eng.farneback_pair(eng.to_device(a), eng.to_device(a))
+
+
+def test_flow_metric_known_answers(eng):           # t.py:706-727
+    z = np.zeros((3, 8, 8), np.uint8)
+    flows, keep = eng.flow_metric(eng.to_device(z))
+    assert np.all(flows.cpu().numpy() == 0.0) and np.all(keep.cpu().numpy() == 1)
+    f0 = np.zeros((10, 10), np.uint8); f1 = f0.copy(); f0[3, 3] = 255; f1[7, 7] = 255
+    flows, _ = eng.flow_metric(eng.to_device(np.stack([f0, f1])))
+    fl = flows.cpu().numpy()
+    assert fl.shape == (2,) and fl[0] == 0.0 and fl[1] > 0.0
+
+
+@pytest.mark.parametrize("shape", [(96, 128), (131, 203)])
+def test_flow_metric_and_keep(eng, shape):
+    from image_processing_amd import synth
+    from oracle import stages as S
+    h, w = shape
+    frames = synth.chunk_numpy(21, 12, h, w, motion_at=(4, 5, 9), shift=5.0)
+    ref = S.compute_optical_flow_metric(frames)
+    flows, keep = eng.flow_metric(eng.to_device(frames))
+    got = flows.cpu().numpy().astype(np.float64)
+    assert got[0] == 0.0
+    assert np.allclose(got, ref, rtol=FLOW_RTOL, atol=1e-12)
+    assert np.array_equal(keep.cpu().numpy().astype(bool), ref <= 2.0)
+    assert not (ref <= 2.0).all() and (ref <= 2.0).sum() >= 6      # the case exercises both branches
+    # left-halo form: flows of frames 5.. given frame 4 as prev_frame
+    fd = eng.to_device(frames)
+    f2, k2 = eng.flow_metric(fd[5:], prev_frame=fd[4])
+    assert np.array_equal(f2.cpu().numpy(), flows.cpu().numpy()[5:])
+    assert np.array_equal(k2.cpu().numpy(), keep.cpu().numpy()[5:])
+
+
+def test_chunk_vs_reference_golden(eng, golden):
+    """ip.detect_damaged_pixels itself (run over the oracle's cv2 restatements) on the 16-frame
+    40x56 chunk with three motion frames: counts, NaNs and cluster metrics, two parameter sets."""
+    ch = golden["hy_frames"]
+    r = eng.detect_chunk(ch)
+    assert np.allclose(r["flows"], golden["hy_flows"], rtol=FLOW_RTOL, atol=1e-12)
+    got = np.stack([r["total_counts"], r["cluster_counts"], r["avg_sizes"], r["avg_brightnesses"]])
+    assert _eq_nan(got, golden["hy_detect"])
+    alt = dict(consecutive_threshold=3, brightness_threshold=150, flow_threshold=0.05, static_threshold=20,
+               min_cluster_size=2, max_cluster_size=12, min_circularity=0.5, sliding_window_radius=2)
+    eng.set_params(alt)
+    r = eng.detect_chunk(ch)
+    got = np.stack([r["total_counts"], r["cluster_counts"], r["avg_sizes"], r["avg_brightnesses"]])
+    eng.set_params(None)
+    assert _eq_nan(got, golden["hy_detect_alt"])
+
+
+@pytest.mark.parametrize("shape,n,kw", [
+    ((96, 128), 24, dict(motion_at=(7, 8, 15), shift=5.0, hot=12.0, stuck=4)),
+    ((131, 203), 16, dict(motion_at=(3,), shift=7.0, hot=20.0, stuck=5, blobs=6)),
+    ((72, 70), 13, dict(hot=9.0)),
+])
+def test_chunk_vs_oracle(eng, shape, n, kw):
+    from image_processing_amd import synth
+    from oracle import pipeline
+    h, w = shape
+    frames = synth.chunk_numpy(100 + h, n, h, w, **kw)
+    (total, cc, sz, br), mid = pipeline.detect_damaged_pixels(frames, return_intermediates=True)
+    r = eng.detect_chunk(frames, want_masks=True)
+    assert np.allclose(r["flows"], mid["flows"], rtol=FLOW_RTOL, atol=1e-12)
+    assert np.array_equal(r["keep"].astype(bool), mid["flows"] <= 2.0)
+    for i in range(n):
+        if mid["final"][i] is None:
+            assert r["final_masks"][i] is None
+        else:
+            assert np.array_equal(r["final_masks"][i], mid["final"][i]), "final mask %d" % i
+    assert _eq_nan(r["total_counts"], total)
+    assert _eq_nan(r["cluster_counts"], cc) and _eq_nan(r["avg_sizes"], sz) and _eq_nan(r["avg_brightnesses"], br)
+    assert np.nansum(total) > 0
+
+
+def test_chunk_is_deterministic_and_matches_stagewise(eng):
+    """Run-to-run bitwise equality, and the fused chunk call equals the stage-by-stage calls."""
+    from image_processing_amd import synth
+    frames = synth.chunk_numpy(77, 20, 120, 200, motion_at=(6,), hot=15.0, stuck=4)
+    fd = eng.to_device(frames)
+    a = eng.detect_chunk_device(fd, want_final_bits=True)
+    b = eng.detect_chunk_device(fd, want_final_bits=True)
+    for k in ("flows", "keep", "counts", "cluster", "final_bits"):
+        assert bool((a[k] == b[k]).all()), k
+    n, h, w = frames.shape
+    flows, keep = eng.flow_metric(fd)
+    raw, bright, dense = eng.detect_raw(fd, keep=keep)
+    raw = eng.remove_bright_regions(bright, raw, h, w)
+    pers = eng.persistent_mask(raw, keep, h, w)
+    st = eng.static_from_maps(eng.static_maps(fd, raw, pers, keep))
+    fin, c3 = eng.finalize(fd, raw, pers, st, keep)
+    cl, _ = eng.cluster_stats(fd, fin, keep)
+    assert bool((fin == a["final_bits"]).all()) and bool((cl == a["cluster"]).all())
+    assert bool((a["counts"][:, :3] == c3).all()) and bool((a["counts"][:, 3:] == dense).all())
