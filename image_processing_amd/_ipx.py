@@ -60,6 +60,11 @@ PROTOTYPES = {
     "ipx_synchronize": (_i, [_ctx]),
     "ipx_timer_begin": (_i, [_ctx]),
     "ipx_timer_end": (_i, [_ctx, C.POINTER(C.c_float)]),
+    "ipx_profile_enable": (_i, [_ctx, _i]),
+    "ipx_profile_reset": (_i, [_ctx]),
+    "ipx_profile_kernel_classes": (_i, []),
+    "ipx_profile_read": (_i, [_ctx, _i, C.POINTER(C.c_char_p), C.POINTER(C.c_uint64), C.POINTER(C.c_double),
+                              C.POINTER(C.c_double)]),
     "ipx_bgr2gray": (_i, [_ctx, _p, C.c_size_t, _p]),
     "ipx_flow_metric": (_i, [_ctx, _p, _i, _i, _i, _p, _p, _p]),
     "ipx_farneback_pair": (_i, [_ctx, _p, _p, _i, _i, _p]),

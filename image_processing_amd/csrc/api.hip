@@ -3,6 +3,7 @@
 #include <math.h>
 #include <stdarg.h>
 #include <string.h>
+#include <stdlib.h>
 
 static thread_local char g_err[512] = "";
 
@@ -69,6 +70,7 @@ extern "C" int ipx_ctx_create(int device, ipx_ctx **out)
     c->stream = nullptr;
     for (int i = 0; i < SLOT_COUNT; ++i) { c->slot[i] = nullptr; c->slot_bytes[i] = 0; }
     c->flow_plan = nullptr;
+    memset(&c->prof, 0, sizeof(c->prof));
     ipx_default_params(&c->p);
     hipError_t e = hipEventCreate(&c->ev0);
     if (e == hipSuccess) e = hipEventCreate(&c->ev1);
@@ -89,6 +91,11 @@ extern "C" int ipx_ctx_destroy(ipx_ctx *ctx)
     for (int i = 0; i < SLOT_COUNT; ++i)
         if (ctx->slot[i]) (void)hipFree(ctx->slot[i]);
     ipx_flow_plan_free(ctx->flow_plan);
+    for (int i = 0; i < ctx->prof.cap; ++i) {
+        (void)hipEventDestroy(ctx->prof.recs[i].e0);
+        (void)hipEventDestroy(ctx->prof.recs[i].e1);
+    }
+    free(ctx->prof.recs);
     (void)hipEventDestroy(ctx->ev0);
     (void)hipEventDestroy(ctx->ev1);
     delete ctx;
@@ -162,6 +169,93 @@ extern "C" int ipx_timer_end(ipx_ctx *ctx, float *elapsed_ms)
     return IPX_OK;
 }
 
+// ---- built-in profiler ----------------------------------------------------------------------
+static const char *const g_kid_names[KID_COUNT] = {
+    "pyr_level", "polyexp", "flow_upsample", "update_matrices", "blur_solve", "magnitude",
+    "detect", "damaged_mask",
+    "ccl_init", "ccl_merge", "ccl_reduce", "ccl_select", "close_cross3", "cluster_eval",
+    "persistent", "static_maps", "static_from_maps", "finalize", "misc",
+};
+
+static int prof_fold(ipx_ctx *ctx)
+{
+    ipx_prof &pr = ctx->prof;
+    if (pr.nrecs == 0) return IPX_OK;
+    IPX_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+    for (int i = 0; i < pr.nrecs; ++i) {
+        float ms = 0.f;
+        IPX_CHECK_HIP(hipEventElapsedTime(&ms, pr.recs[i].e0, pr.recs[i].e1));
+        pr.ms[pr.recs[i].kid] += ms;
+        pr.bytes[pr.recs[i].kid] += pr.recs[i].bytes;
+        pr.launches[pr.recs[i].kid] += 1;
+    }
+    pr.nrecs = 0;
+    return IPX_OK;
+}
+
+void ipx_prof_begin(ipx_ctx *ctx, int kid, double bytes)
+{
+    ipx_prof &pr = ctx->prof;
+    if (pr.nrecs == pr.cap) {
+        if (pr.cap >= (1 << 15)) {                 // bound the pool: fold what is pending (synchronises)
+            if (prof_fold(ctx) != IPX_OK) { pr.on = 0; return; }
+        } else {
+            const int ncap = pr.cap ? pr.cap * 2 : 256;
+            ipx_prof_rec *nr = (ipx_prof_rec *)realloc(pr.recs, sizeof(ipx_prof_rec) * ncap);
+            if (!nr) { pr.on = 0; return; }
+            pr.recs = nr;
+            for (int i = pr.cap; i < ncap; ++i) {
+                if (hipEventCreate(&nr[i].e0) != hipSuccess || hipEventCreate(&nr[i].e1) != hipSuccess) { pr.on = 0; pr.cap = i; return; }
+            }
+            pr.cap = ncap;
+        }
+    }
+    ipx_prof_rec &r = pr.recs[pr.nrecs];
+    r.kid = kid; r.bytes = bytes;
+    (void)hipEventRecord(r.e0, ctx->stream);
+}
+
+void ipx_prof_end(ipx_ctx *ctx)
+{
+    ipx_prof &pr = ctx->prof;
+    if (!pr.on) return;
+    (void)hipEventRecord(pr.recs[pr.nrecs].e1, ctx->stream);
+    pr.nrecs++;
+}
+
+extern "C" int ipx_profile_enable(ipx_ctx *ctx, int on)
+{
+    IPX_REQUIRE(ctx, "null pointer");
+    if (int e = ipx_ctx_enter(ctx)) return e;
+    if (int e = prof_fold(ctx)) return e;
+    ctx->prof.on = on ? 1 : 0;
+    return IPX_OK;
+}
+
+extern "C" int ipx_profile_reset(ipx_ctx *ctx)
+{
+    IPX_REQUIRE(ctx, "null pointer");
+    if (int e = ipx_ctx_enter(ctx)) return e;
+    if (int e = prof_fold(ctx)) return e;
+    for (int k = 0; k < KID_COUNT; ++k) { ctx->prof.ms[k] = 0; ctx->prof.bytes[k] = 0; ctx->prof.launches[k] = 0; }
+    return IPX_OK;
+}
+
+extern "C" int ipx_profile_kernel_classes(void) { return KID_COUNT; }
+
+extern "C" int ipx_profile_read(ipx_ctx *ctx, int kid, const char **name, uint64_t *launches, double *total_ms,
+                                double *total_bytes)
+{
+    IPX_REQUIRE(ctx && kid >= 0 && kid < KID_COUNT, "bad kernel class");
+    if (int e = ipx_ctx_enter(ctx)) return e;
+    if (int e = prof_fold(ctx)) return e;
+    if (name) *name = g_kid_names[kid];
+    if (launches) *launches = ctx->prof.launches[kid];
+    if (total_ms) *total_ms = ctx->prof.ms[kid];
+    if (total_bytes) *total_bytes = ctx->prof.bytes[kid];
+    return IPX_OK;
+}
+
 // ---- helper kernels ------------------------------------------------------------------------
 namespace {
 
@@ -207,7 +301,7 @@ extern "C" int ipx_bgr2gray(ipx_ctx *ctx, const uint8_t *bgr, size_t npix, uint8
     if (npix == 0) return IPX_OK;
     if (int e = ipx_ctx_enter(ctx)) return e;
     const int blocks = (int)((npix + 255) / 256 < 4096 ? (npix + 255) / 256 : 4096);
-    hipLaunchKernelGGL(bgr2gray_kernel, dim3(blocks), dim3(256), 0, ctx->stream, bgr, npix, gray);
+    IPX_LAUNCH(ctx, KID_MISC, 4.0 * npix, bgr2gray_kernel, dim3(blocks), dim3(256), bgr, npix, gray);
     IPX_LAUNCH_CHECK();
     return IPX_OK;
 }
@@ -219,7 +313,7 @@ extern "C" int ipx_pack_mask(ipx_ctx *ctx, const uint8_t *mask, int count, int H
     if (int e = ipx_ctx_enter(ctx)) return e;
     const int wpr = ipx_wpr(W);
     const size_t words = (size_t)count * H * wpr;
-    hipLaunchKernelGGL(pack_kernel, dim3((unsigned)((words + 3) / 4)), dim3(256), 0, ctx->stream, mask,
+    IPX_LAUNCH(ctx, KID_MISC, (double)count * H * W + words * 8.0, pack_kernel, dim3((unsigned)((words + 3) / 4)), dim3(256), mask,
                        count * H, W, wpr, bits);
     IPX_LAUNCH_CHECK();
     return IPX_OK;
@@ -231,7 +325,7 @@ extern "C" int ipx_unpack_mask(ipx_ctx *ctx, const uint64_t *bits, int count, in
     IPX_REQUIRE(count > 0 && H > 0 && W > 0, "bad sizes");
     if (int e = ipx_ctx_enter(ctx)) return e;
     const size_t n = (size_t)count * H * W;
-    hipLaunchKernelGGL(unpack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, bits,
+    IPX_LAUNCH(ctx, KID_MISC, (double)n + (double)count * H * ipx_wpr(W) * 8, unpack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), bits,
                        count * H, W, ipx_wpr(W), mask);
     IPX_LAUNCH_CHECK();
     return IPX_OK;

@@ -447,14 +447,14 @@ extern "C" int ipx_remove_bright_regions(ipx_ctx *ctx, const uint64_t *bright_bi
         uint64_t *ob = out_bits + first * pl.words;
         const size_t nw = pl.words * nb;
         const dim3 grid((unsigned)((nw + 255) / 256)), block(256);
-        hipLaunchKernelGGL(ccl_init_kernel, grid, block, 0, ctx->stream, bb, pl, nb, par, aux0, (unsigned *)nullptr);
-        hipLaunchKernelGGL(ccl_merge_kernel, grid, block, 0, ctx->stream, bb, pl, nb, par);
-        hipLaunchKernelGGL(ccl_area_kernel, grid, block, 0, ctx->stream, bb, pl, nb, par, aux0);
-        hipLaunchKernelGGL(select_big_kernel, grid, block, 0, ctx->stream, bb, pl, nb, par, aux0, min_area, remove);
-        hipLaunchKernelGGL(ccl_init_kernel, grid, block, 0, ctx->stream, db, pl, nb, par, aux0, (unsigned *)nullptr);
-        hipLaunchKernelGGL(ccl_merge_kernel, grid, block, 0, ctx->stream, db, pl, nb, par);
-        hipLaunchKernelGGL(ccl_taint_kernel, grid, block, 0, ctx->stream, db, remove, pl, nb, par, aux0);
-        hipLaunchKernelGGL(select_untainted_kernel, grid, block, 0, ctx->stream, db, pl, nb, par, aux0, ob);
+        IPX_LAUNCH(ctx, KID_CCL_INIT, nw * 8, ccl_init_kernel, grid, block, bb, pl, nb, par, aux0, (unsigned *)nullptr);
+        IPX_LAUNCH(ctx, KID_CCL_MERGE, nw * 8, ccl_merge_kernel, grid, block, bb, pl, nb, par);
+        IPX_LAUNCH(ctx, KID_CCL_REDUCE, nw * 8, ccl_area_kernel, grid, block, bb, pl, nb, par, aux0);
+        IPX_LAUNCH(ctx, KID_CCL_SELECT, nw * 16, select_big_kernel, grid, block, bb, pl, nb, par, aux0, min_area, remove);
+        IPX_LAUNCH(ctx, KID_CCL_INIT, nw * 8, ccl_init_kernel, grid, block, db, pl, nb, par, aux0, (unsigned *)nullptr);
+        IPX_LAUNCH(ctx, KID_CCL_MERGE, nw * 8, ccl_merge_kernel, grid, block, db, pl, nb, par);
+        IPX_LAUNCH(ctx, KID_CCL_REDUCE, nw * 16, ccl_taint_kernel, grid, block, db, remove, pl, nb, par, aux0);
+        IPX_LAUNCH(ctx, KID_CCL_SELECT, nw * 16, select_untainted_kernel, grid, block, db, pl, nb, par, aux0, ob);
         IPX_LAUNCH_CHECK();
     }
     return IPX_OK;
@@ -494,14 +494,14 @@ extern "C" int ipx_cluster_stats(ipx_ctx *ctx, const uint8_t *frames, const uint
         const uint8_t *kp = keep ? keep + first : nullptr;
         const size_t nw = pl.words * nb;
         const dim3 grid((unsigned)((nw + 255) / 256)), block(256);
-        hipLaunchKernelGGL(close_cross3_kernel, grid, block, 0, ctx->stream, mb, pl, nb, kp, closed);
-        hipLaunchKernelGGL(ccl_init_kernel, grid, block, 0, ctx->stream, closed, pl, nb, par, aux0, aux1);
-        hipLaunchKernelGGL(ccl_merge_kernel, grid, block, 0, ctx->stream, closed, pl, nb, par);
-        hipLaunchKernelGGL(cluster_accum_kernel, grid, block, 0, ctx->stream, closed, fr, pl, nb, par, aux0, aux1);
-        hipLaunchKernelGGL(cluster_eval_kernel, grid, block, 0, ctx->stream, closed, pl, nb, par, aux0, aux1, ca,
+        IPX_LAUNCH(ctx, KID_CLOSE, nw * 16, close_cross3_kernel, grid, block, mb, pl, nb, kp, closed);
+        IPX_LAUNCH(ctx, KID_CCL_INIT, nw * 8, ccl_init_kernel, grid, block, closed, pl, nb, par, aux0, aux1);
+        IPX_LAUNCH(ctx, KID_CCL_MERGE, nw * 8, ccl_merge_kernel, grid, block, closed, pl, nb, par);
+        IPX_LAUNCH(ctx, KID_CCL_REDUCE, nw * 8, cluster_accum_kernel, grid, block, closed, fr, pl, nb, par, aux0, aux1);
+        IPX_LAUNCH(ctx, KID_CLUSTER_EVAL, nw * 8, cluster_eval_kernel, grid, block, closed, pl, nb, par, aux0, aux1, ca,
                            (unsigned long long *)stats + (size_t)first * 3);
         if (cleaned_bits)
-            hipLaunchKernelGGL(select_marked_kernel, grid, block, 0, ctx->stream, closed, pl, nb, par, aux0,
+            IPX_LAUNCH(ctx, KID_CCL_SELECT, nw * 16, select_marked_kernel, grid, block, closed, pl, nb, par, aux0,
                                cleaned_bits + first * pl.words);
         IPX_LAUNCH_CHECK();
     }

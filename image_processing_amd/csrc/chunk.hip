@@ -49,7 +49,7 @@ extern "C" int ipx_detect_chunk(ipx_ctx *ctx, const uint8_t *frames, int n, int 
     IPX_TRY(ipx_finalize(ctx, frames, (const uint64_t *)raw, (const uint64_t *)pers, (const uint64_t *)stat, keep, n, H, W,
                          (uint64_t *)fin, fin3));                                                 // :592-605
     IPX_TRY(ipx_cluster_stats(ctx, frames, (const uint64_t *)fin, keep, n, H, W, pow2_table, tdim, cluster, nullptr));   // :608
-    hipLaunchKernelGGL(merge_counts_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, fin3, dense2, n, counts);
+    IPX_LAUNCH(ctx, KID_MISC, 80.0 * n, merge_counts_kernel, dim3((n + 255) / 256), dim3(256), fin3, dense2, n, counts);
     IPX_LAUNCH_CHECK();
     return IPX_OK;
 }

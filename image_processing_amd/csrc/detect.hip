@@ -284,8 +284,14 @@ static int launch_detect(ipx_ctx *ctx, const uint8_t *frames, int n, int H, int 
         IPX_CHECK_HIP(hipMemsetAsync(dense_counts, 0, sizeof(int64_t) * 2 * (size_t)count, ctx->stream));
     dim3 grid((W + TW - 1) / TW, (H + TH - 1) / TH, count), block(256);
     const int r = ctx->p.sliding_window_radius;
-    if (r <= 3) hipLaunchKernelGGL(detect_kernel<6>, grid, block, 0, ctx->stream, a);
-    else if (r <= 8) hipLaunchKernelGGL(detect_kernel<16>, grid, block, 0, ctx->stream, a);
+    // algorithmic bytes: centre frame + its temporal neighbours read once, two bit-planes written
+    double ab = 2.0 * count * H * ipx_wpr(W) * 8;
+    for (int i = first; i < first + count; ++i) {
+        const int lo = i - r < 0 ? 0 : i - r, hi = i + r + 1 > n ? n : i + r + 1;
+        ab += (double)(hi - lo) * H * W;
+    }
+    if (r <= 3) IPX_LAUNCH(ctx, KID_DETECT, ab, detect_kernel<6>, grid, block, a);
+    else if (r <= 8) IPX_LAUNCH(ctx, KID_DETECT, ab, detect_kernel<16>, grid, block, a);
     else {
         ipx_set_error("sliding_window_radius %d > 8 is not supported by the HIP path", r);
         return IPX_ERR_UNSUPPORTED;
@@ -326,10 +332,10 @@ extern "C" int ipx_damaged_mask(ipx_ctx *ctx, const uint8_t *frame, int H, int W
     if (int e = ipx_ctx_enter(ctx)) return e;
     dim3 grid((W + 63) / 64, H), block(64);
     if (bg_is_f64)
-        hipLaunchKernelGGL(damaged_mask_kernel<double>, grid, block, 0, ctx->stream, frame, H, W,
+        IPX_LAUNCH(ctx, KID_DAMAGED_MASK, (double)H * W * (bg_is_f64 ? 18 : 10), damaged_mask_kernel<double>, grid, block, frame, H, W,
                            (const double *)bg, mask, (double *)thr);
     else
-        hipLaunchKernelGGL(damaged_mask_kernel<float>, grid, block, 0, ctx->stream, frame, H, W,
+        IPX_LAUNCH(ctx, KID_DAMAGED_MASK, (double)H * W * (bg_is_f64 ? 18 : 10), damaged_mask_kernel<float>, grid, block, frame, H, W,
                            (const float *)bg, mask, (float *)thr);
     IPX_LAUNCH_CHECK();
     return IPX_OK;

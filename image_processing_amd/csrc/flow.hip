@@ -565,15 +565,14 @@ int launch_level_expansion(ipx_ctx *ctx, const LevelGeom &g, const uint8_t *fram
     memcpy(a.kt.k, g.kern, sizeof(a.kt.k));
     const dim3 grid = grid64x4(g.lw, g.lh, nf), block(256);
     switch (g.ksize) {
-    case 3: hipLaunchKernelGGL(pyr_level_kernel<3>, grid, block, 0, ctx->stream, a); break;
-    case 9: hipLaunchKernelGGL(pyr_level_kernel<9>, grid, block, 0, ctx->stream, a); break;
-    case 19: hipLaunchKernelGGL(pyr_level_kernel<19>, grid, block, 0, ctx->stream, a); break;
+    case 3: IPX_LAUNCH(ctx, KID_PYR, (double)nf * ((double)pl->H * pl->W + 4.0 * g.lh * g.lw), pyr_level_kernel<3>, grid, block, a); break;
+    case 9: IPX_LAUNCH(ctx, KID_PYR, (double)nf * ((double)pl->H * pl->W + 4.0 * g.lh * g.lw), pyr_level_kernel<9>, grid, block, a); break;
+    case 19: IPX_LAUNCH(ctx, KID_PYR, (double)nf * ((double)pl->H * pl->W + 4.0 * g.lh * g.lw), pyr_level_kernel<19>, grid, block, a); break;
     default:
         ipx_set_error("Gaussian aperture %d unsupported", g.ksize);
         return IPX_ERR_UNSUPPORTED;
     }
-    hipLaunchKernelGGL(polyexp_kernel, dim3((g.lw + PX_TW - 1) / PX_TW, (g.lh + PX_TH - 1) / PX_TH, nf), block, 0,
-                       ctx->stream, I, g.lh, g.lw, pl->pc, R);
+    IPX_LAUNCH(ctx, KID_POLYEXP, 24.0 * nf * g.lh * g.lw, polyexp_kernel, dim3((g.lw + PX_TW - 1) / PX_TW, (g.lh + PX_TH - 1) / PX_TH, nf), block, I, g.lh, g.lw, pl->pc, R);
     IPX_LAUNCH_CHECK();
     return IPX_OK;
 }
@@ -604,15 +603,15 @@ int run_pairs(ipx_ctx *ctx, const uint8_t *frames, const uint8_t *extra, int fir
             IPX_CHECK_HIP(hipMemsetAsync(cur, 0, (size_t)np * P * sizeof(float2), ctx->stream));
         } else {
             const LevelGeom &c = pl->lv[k + 1];
-            hipLaunchKernelGGL(flow_upsample_kernel, grid64x4(g.lw, g.lh, np), block, 0, ctx->stream, prev, c.lh, c.lw,
+            IPX_LAUNCH(ctx, KID_UPSAMPLE, 8.0 * np * ((double)g.lh * g.lw + (double)c.lh * c.lw), flow_upsample_kernel, grid64x4(g.lw, g.lh, np), block, prev, c.lh, c.lw,
                                cur, g.lh, g.lw, g.ux_ofs, g.ux_a, g.uy_ofs, g.uy_b);
         }
-        hipLaunchKernelGGL(update_matrices_kernel, grid64x4(g.lw, g.lh, np), block, 0, ctx->stream, R, cur, g.lh, g.lw, M);
+        IPX_LAUNCH(ctx, KID_UPDATE_MATRICES, 68.0 * np * P, update_matrices_kernel, grid64x4(g.lw, g.lh, np), block, R, cur, g.lh, g.lw, M);
         const dim3 bgrid((g.lw + BS_TW - 1) / BS_TW, (g.lh + BS_TH - 1) / BS_TH, np);
         for (int it = 0; it < 3; ++it) {                            // ip.py:864 iterations=3
-            hipLaunchKernelGGL(blur_solve_kernel, bgrid, block, 0, ctx->stream, M, g.lh, g.lw, cur);
+            IPX_LAUNCH(ctx, KID_BLUR_SOLVE, 28.0 * np * P, blur_solve_kernel, bgrid, block, M, g.lh, g.lw, cur);
             if (it < 2)
-                hipLaunchKernelGGL(update_matrices_kernel, grid64x4(g.lw, g.lh, np), block, 0, ctx->stream, R, cur, g.lh, g.lw, M);
+                IPX_LAUNCH(ctx, KID_UPDATE_MATRICES, 68.0 * np * P, update_matrices_kernel, grid64x4(g.lw, g.lh, np), block, R, cur, g.lh, g.lw, M);
         }
         IPX_LAUNCH_CHECK();
         prev = cur;
@@ -643,7 +642,7 @@ extern "C" int ipx_flow_metric(ipx_ctx *ctx, const uint8_t *frames, int n, int H
     IPX_TRY(build_plan(ctx, H, W));
     const size_t P = (size_t)H * W;
     const int first_pair = prev_frame ? 0 : 1;       // pair i = (frame i-1, frame i)
-    if (!prev_frame) hipLaunchKernelGGL(first_frame_kernel, dim3(1), dim3(1), 0, ctx->stream, flows, keep);
+    if (!prev_frame) IPX_LAUNCH(ctx, KID_MISC, 5, first_frame_kernel, dim3(1), dim3(1), flows, keep);
     const int total = n - first_pair;
     if (total <= 0) { IPX_LAUNCH_CHECK(); return IPX_OK; }
     const int B = pair_batch(H, W, total);
@@ -653,8 +652,8 @@ extern "C" int ipx_flow_metric(ipx_ctx *ctx, const uint8_t *frames, int n, int H
         const int np = n - i0 < B ? n - i0 : B;
         float2 *uv;
         IPX_TRY(run_pairs(ctx, frames, prev_frame, i0 - 1, np, &uv));
-        hipLaunchKernelGGL(magnitude_partial_kernel, dim3(RED_BLOCKS, np), dim3(256), 0, ctx->stream, uv, P, (double *)red);
-        hipLaunchKernelGGL(magnitude_finish_kernel, dim3((np + 63) / 64), dim3(64), 0, ctx->stream, (const double *)red, P, np,
+        IPX_LAUNCH(ctx, KID_MAGNITUDE, 8.0 * np * P, magnitude_partial_kernel, dim3(RED_BLOCKS, np), dim3(256), uv, P, (double *)red);
+        IPX_LAUNCH(ctx, KID_MISC, 8.0 * RED_BLOCKS * np, magnitude_finish_kernel, dim3((np + 63) / 64), dim3(64), (const double *)red, P, np,
                            ctx->p.flow_threshold, flows + i0, keep ? keep + i0 : nullptr);
         IPX_LAUNCH_CHECK();
     }
@@ -688,8 +687,8 @@ extern "C" int ipx_farneback_pair(ipx_ctx *ctx, const float *prev, const float *
     int *bad = (int *)(u8 + ipx_align_up(2 * P, 16));
     IPX_CHECK_HIP(hipMemsetAsync(bad, 0, sizeof(int), ctx->stream));
     const dim3 grid((unsigned)((P + 255) / 256)), block(256);
-    hipLaunchKernelGGL(f32_to_u8_kernel, grid, block, 0, ctx->stream, prev, P, u8, bad);
-    hipLaunchKernelGGL(f32_to_u8_kernel, grid, block, 0, ctx->stream, next, P, u8 + P, bad);
+    IPX_LAUNCH(ctx, KID_MISC, 5.0 * P, f32_to_u8_kernel, grid, block, prev, P, u8, bad);
+    IPX_LAUNCH(ctx, KID_MISC, 5.0 * P, f32_to_u8_kernel, grid, block, next, P, u8 + P, bad);
     IPX_LAUNCH_CHECK();
     int hbad = 0;
     IPX_CHECK_HIP(hipMemcpyAsync(&hbad, bad, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));

@@ -23,6 +23,25 @@ enum ipx_slot {
 
 struct ipx_flow_plan;   // flow.hip
 
+// Kernel classes of the built-in profiler (ipx_profile_*): HIP events recorded on the context's
+// stream around every launch, accumulated per class together with the launch's ALGORITHMIC bytes
+// (compulsory reads + writes: every input and output array counted once; DESIGN.md lists them).
+enum ipx_kid {
+    KID_PYR = 0, KID_POLYEXP, KID_UPSAMPLE, KID_UPDATE_MATRICES, KID_BLUR_SOLVE, KID_MAGNITUDE,
+    KID_DETECT, KID_DAMAGED_MASK,
+    KID_CCL_INIT, KID_CCL_MERGE, KID_CCL_REDUCE, KID_CCL_SELECT, KID_CLOSE, KID_CLUSTER_EVAL,
+    KID_PERSISTENT, KID_STATIC_MAPS, KID_STATIC_FROM_MAPS, KID_FINALIZE, KID_MISC,
+    KID_COUNT
+};
+
+struct ipx_prof_rec { int kid; double bytes; hipEvent_t e0, e1; };
+struct ipx_prof {
+    int on;
+    ipx_prof_rec *recs; int nrecs, cap;     // pending (not yet folded) launches; events are reused
+    double ms[KID_COUNT], bytes[KID_COUNT];
+    unsigned long long launches[KID_COUNT];
+};
+
 struct ipx_ctx {
     int device;
     hipStream_t stream;
@@ -31,7 +50,19 @@ struct ipx_ctx {
     size_t slot_bytes[SLOT_COUNT];
     hipEvent_t ev0, ev1;
     ipx_flow_plan *flow_plan;   // cached tables for the last (H,W) seen by the flow stage
+    ipx_prof prof;
 };
+
+void ipx_prof_begin(ipx_ctx *ctx, int kid, double bytes);
+void ipx_prof_end(ipx_ctx *ctx);
+
+// Launch `kernel` on the context's stream; `abytes` = algorithmic bytes of this launch.
+#define IPX_LAUNCH(ctx, kid, abytes, kernel, grid, block, ...)                          \
+    do {                                                                               \
+        if ((ctx)->prof.on) ipx_prof_begin((ctx), (kid), (double)(abytes));            \
+        hipLaunchKernelGGL(kernel, grid, block, 0, (ctx)->stream, __VA_ARGS__);        \
+        if ((ctx)->prof.on) ipx_prof_end(ctx);                                         \
+    } while (0)
 
 void ipx_set_error(const char *fmt, ...);
 

@@ -180,15 +180,15 @@ extern "C" int ipx_persistent_mask(ipx_ctx *ctx, const uint64_t *raw_bits, const
     const dim3 grid((unsigned)((words + 255) / 256)), block(256);
     const int T = ctx->p.consecutive_threshold;
     if (T <= 0) {                     // longest >= T holds for every pixel, ip.py:289
-        hipLaunchKernelGGL(fill_plane_kernel, grid, block, 0, ctx->stream, persistent_bits, H, W, wpr);
+        IPX_LAUNCH(ctx, KID_PERSISTENT, words * 8, fill_plane_kernel, grid, block, persistent_bits, H, W, wpr);
     } else if (T > n) {               // no run can be that long
         IPX_CHECK_HIP(hipMemsetAsync(persistent_bits, 0, words * 8, ctx->stream));
     } else if (T < 4) {
-        hipLaunchKernelGGL(persistent_kernel<2>, grid, block, 0, ctx->stream, raw_bits, keep, n, words, T, 0ull, persistent_bits);
+        IPX_LAUNCH(ctx, KID_PERSISTENT, (n + 1.0) * words * 8, persistent_kernel<2>, grid, block, raw_bits, keep, n, words, T, 0ull, persistent_bits);
     } else if (T < 256) {
-        hipLaunchKernelGGL(persistent_kernel<8>, grid, block, 0, ctx->stream, raw_bits, keep, n, words, T, 0ull, persistent_bits);
+        IPX_LAUNCH(ctx, KID_PERSISTENT, (n + 1.0) * words * 8, persistent_kernel<8>, grid, block, raw_bits, keep, n, words, T, 0ull, persistent_bits);
     } else {
-        hipLaunchKernelGGL(persistent_kernel<24>, grid, block, 0, ctx->stream, raw_bits, keep, n, words, T, 0ull, persistent_bits);
+        IPX_LAUNCH(ctx, KID_PERSISTENT, (n + 1.0) * words * 8, persistent_kernel<24>, grid, block, raw_bits, keep, n, words, T, 0ull, persistent_bits);
     }
     IPX_LAUNCH_CHECK();
     return IPX_OK;
@@ -204,7 +204,7 @@ extern "C" int ipx_static_maps(ipx_ctx *ctx, const uint8_t *frames, const uint64
     const ipx_derived d = ipx_derive(ctx->p);
     const int quads = (W + 3) / 4;
     const dim3 grid((quads + 63) / 64, H), block(64);
-    hipLaunchKernelGGL(static_maps_kernel, grid, block, 0, ctx->stream, frames, raw_bits, persistent_bits, keep,
+    IPX_LAUNCH(ctx, KID_STATIC_MAPS, (double)n * ((double)H * W + (double)H * ipx_wpr(W) * 8) + 8.0 * H * W + (double)H * ipx_wpr(W) * 8, static_maps_kernel, grid, block, frames, raw_bits, persistent_bits, keep,
                        n, H, W, ipx_wpr(W), d.frame_gt, heat, valid);
     IPX_LAUNCH_CHECK();
     return IPX_OK;
@@ -218,8 +218,7 @@ extern "C" int ipx_static_from_maps(ipx_ctx *ctx, const int32_t *heat, const int
     if (int e = ipx_ctx_enter(ctx)) return e;
     const int wpr = ipx_wpr(W);
     const size_t words = (size_t)H * wpr;
-    hipLaunchKernelGGL(static_from_maps_kernel, dim3((unsigned)((words + 3) / 4)), dim3(256), 0, ctx->stream,
-                       heat, valid, H, W, wpr, ctx->p.min_valid_frames, ctx->p.static_threshold, static_bits);
+    IPX_LAUNCH(ctx, KID_STATIC_FROM_MAPS, 8.0 * H * W + words * 8, static_from_maps_kernel, dim3((unsigned)((words + 3) / 4)), dim3(256), heat, valid, H, W, wpr, ctx->p.min_valid_frames, ctx->p.static_threshold, static_bits);
     IPX_LAUNCH_CHECK();
     return IPX_OK;
 }
@@ -236,7 +235,7 @@ extern "C" int ipx_finalize(ipx_ctx *ctx, const uint8_t *frames, const uint64_t 
     const size_t words = (size_t)H * wpr;
     IPX_CHECK_HIP(hipMemsetAsync(counts, 0, sizeof(int64_t) * 3 * (size_t)n, ctx->stream));
     const dim3 grid((unsigned)((words + 255) / 256), n), block(256);
-    hipLaunchKernelGGL(finalize_kernel, grid, block, 0, ctx->stream, frames, raw_bits, persistent_bits, static_bits,
+    IPX_LAUNCH(ctx, KID_FINALIZE, (2.0 * n + 2.0) * words * 8, finalize_kernel, grid, block, frames, raw_bits, persistent_bits, static_bits,
                        keep, H, W, wpr, d.est_lt, d.frame_gt, final_bits, (unsigned long long *)counts);
     IPX_LAUNCH_CHECK();
     return IPX_OK;
@@ -248,7 +247,7 @@ extern "C" int ipx_or_planes(ipx_ctx *ctx, const uint64_t *planes, int count, in
     IPX_REQUIRE(count > 0 && H > 0 && W > 0, "bad sizes");
     if (int e = ipx_ctx_enter(ctx)) return e;
     const size_t words = (size_t)H * ipx_wpr(W);
-    hipLaunchKernelGGL(or_planes_kernel, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, ctx->stream, planes, count,
+    IPX_LAUNCH(ctx, KID_MISC, (count + 1.0) * words * 8, or_planes_kernel, dim3((unsigned)((words + 255) / 256)), dim3(256), planes, count,
                        words, out);
     IPX_LAUNCH_CHECK();
     return IPX_OK;

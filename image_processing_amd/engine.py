@@ -92,6 +92,24 @@ class Engine:
         check(lib.ipx_timer_end(self._ctx, C.byref(ms)))
         return ms.value
 
+    # ---- built-in per-kernel profiler (HIP events on the launch stream) -----------------------------
+    def profile_enable(self, on=True):
+        self._enter()
+        check(lib.ipx_profile_enable(self._ctx, int(bool(on))))
+
+    def profile_reset(self):
+        check(lib.ipx_profile_reset(self._ctx))
+
+    def profile_read(self):
+        """{kernel class: dict(launches, ms, bytes)} accumulated since the last reset (synchronises)."""
+        out = {}
+        for k in range(lib.ipx_profile_kernel_classes()):
+            name, n, ms, by = C.c_char_p(), C.c_uint64(), C.c_double(), C.c_double()
+            check(lib.ipx_profile_read(self._ctx, k, C.byref(name), C.byref(n), C.byref(ms), C.byref(by)))
+            if n.value:
+                out[name.value.decode()] = dict(launches=int(n.value), ms=ms.value, bytes=by.value)
+        return out
+
     # ---- stages on device tensors ------------------------------------------------------------------
     def bgr2gray(self, bgr):
         assert bgr.dtype == torch.uint8 and bgr.is_contiguous() and bgr.shape[-1] == 3

@@ -78,6 +78,16 @@ int ipx_synchronize(ipx_ctx *ctx);
 int ipx_timer_begin(ipx_ctx *ctx);
 int ipx_timer_end(ipx_ctx *ctx, float *elapsed_ms);             /* synchronises               */
 
+/* Built-in per-kernel profiler (no counterpart in the reference; bench.py's roofline uses it).
+ * While enabled, HIP events are recorded on the context's stream around every kernel launch and
+ * accumulated per kernel class with the launch's algorithmic bytes.  ipx_profile_read
+ * synchronises the stream. */
+int ipx_profile_enable(ipx_ctx *ctx, int on);
+int ipx_profile_reset(ipx_ctx *ctx);
+int ipx_profile_kernel_classes(void);
+int ipx_profile_read(ipx_ctx *ctx, int kernel_class, const char **name, uint64_t *launches,
+                     double *total_ms, double *total_bytes);
+
 /* ---- a1: load_video_frames' grey conversion, ip.py:78-79 (cv2.cvtColor BGR2GRAY) --------- */
 int ipx_bgr2gray(ipx_ctx *ctx, const uint8_t *bgr, size_t npix, uint8_t *gray);
 
