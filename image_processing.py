@@ -1,0 +1,782 @@
+"""image_processing -- drop-in for Ben-Folkard/image_processing's module of the same name, with the
+per-frame damaged-pixel detection path running as gfx950 HIP kernels (libipx.so, include/ipx.h).
+
+Same module-level names, positional / keyword signatures and return conventions as the reference
+(``ip.py`` = /root/reference/image_processing.py; each function cites the lines it mirrors), plus
+the call forms of the newer API generation that the reference's own test file uses (SURVEY.md
+section 4).  Frames are uint8 greyscale footage: the GPU kernels compute on the integer pixel
+values, so float arrays are accepted only when they hold integers in [0, 255] (which is what the
+reference's ``astype`` calls produce); anything else raises ``ValueError`` -- there is no CPU path.
+
+``detect_damaged_pixels`` runs the whole chunk in one library call (``ipx_detect_chunk``) while the
+stage functions below are the module's own; if a caller has replaced any of them (the reference's
+tests monkeypatch stages), it runs stage by stage through the module globals exactly in the
+reference's order instead.
+"""
+import math
+import os
+
+import numpy as np
+
+try:                                    # decode only; optional (ip.py:18 imports it unconditionally)
+    import cv2
+except ImportError:                     # pragma: no cover - depends on the environment
+    cv2 = None
+
+try:
+    import matplotlib.pyplot as plt
+    import matplotlib.patches as mpatches
+    HAS_MATPLOTLIB = True
+except ImportError:                     # ip.py:26-33
+    HAS_MATPLOTLIB = False
+    plt = None
+    mpatches = None
+
+from image_processing_amd import avi as _avi
+from image_processing_amd import hostmath as _hostmath
+
+_ENGINE = None
+
+
+def _engine():
+    """The process-wide libipx context on the current torch device (created on first use)."""
+    global _ENGINE
+    if _ENGINE is None:
+        import torch
+        from image_processing_amd.engine import Engine
+        _ENGINE = Engine(torch.cuda.current_device() if torch.cuda.is_available() else 0)
+    return _ENGINE
+
+
+class _Scoped:
+    """Set engine parameters for one call, restore the previous ones afterwards."""
+
+    def __init__(self, **params):
+        self.params = params
+
+    def __enter__(self):
+        self.eng = _engine()
+        self.saved = {k: getattr(self.eng.params, k) for k, _ in self.eng.params._fields_ if k != "reserved0"}
+        merged = dict(self.saved)
+        merged.update(self.params)
+        self.eng.set_params(merged)
+        return self.eng
+
+    def __exit__(self, *exc):
+        self.eng.set_params(self.saved)
+        return False
+
+
+def _as_u8(a, what="frames"):
+    """uint8 view of footage given as any dtype holding integers in [0, 255]."""
+    a = np.asarray(a)
+    if a.dtype == np.uint8:
+        return np.ascontiguousarray(a)
+    if a.dtype == bool:
+        return np.ascontiguousarray(a, dtype=np.uint8)
+    r = a.astype(np.uint8)
+    if not np.array_equal(r, a):
+        raise ValueError("%s must hold integer values in [0, 255] (8-bit footage); the HIP path has no "
+                         "float-image mode" % what)
+    return np.ascontiguousarray(r)
+
+
+def _stack_masks(masks, shape=None):
+    """list of bool arrays / None -> (keep u8 (n,), stacked bool (n,H,W))."""
+    if shape is None:
+        shape = next(np.asarray(m).shape for m in masks if m is not None)
+    keep = np.array([m is not None for m in masks], np.uint8)
+    st = np.zeros((len(masks),) + tuple(shape), bool)
+    for i, m in enumerate(masks):
+        if m is not None:
+            st[i] = np.asarray(m).astype(bool)
+    return keep, st
+
+
+def _bits(eng, masks_bool):
+    import torch
+    return eng.pack_mask(torch.from_numpy(np.ascontiguousarray(masks_bool)).to(eng.device))
+
+
+def _unbits(eng, bits, H, W):
+    if bits.dim() == 2:
+        bits = bits[None]
+    return eng.unpack_mask(bits, H, W).cpu().numpy().astype(bool)
+
+
+# ---------------------------------------------------------------------------------------------
+# video input (ip.py:38-85, 137-149)
+# ---------------------------------------------------------------------------------------------
+def download_video_from_url(url, filename):
+    """ip.py:38-53."""
+    import requests
+    response = requests.get(url)
+    if response.status_code == 200:
+        with open(filename, "wb") as f:
+            f.write(response.content)
+        print(f"Downloaded video as {filename}")
+    else:
+        print("Failed to download video")
+    return filename
+
+
+def _open_capture(filename):
+    if cv2 is not None:
+        return cv2.VideoCapture(filename), cv2.CAP_PROP_POS_FRAMES
+    return _avi.VideoCapture(filename), _avi.VideoCapture.CAP_PROP_POS_FRAMES
+
+
+def _to_grey(frame):
+    """cv2.cvtColor(frame, COLOR_BGR2GRAY) (ip.py:79) on the GPU: ipx_bgr2gray."""
+    eng = _engine()
+    return eng.bgr2gray(eng.to_device(np.ascontiguousarray(frame[..., :3], dtype=np.uint8))).cpu().numpy()
+
+
+def load_video_frames(filename, frames_start=None, frames_end=None, grayscale=True):
+    """ip.py:56-85: list of frames [frames_start, frames_end) as 2-D uint8 greyscale arrays.
+    Decoding is cv2.VideoCapture when cv2 is importable, else the uncompressed-AVI reader."""
+    cap, pos_prop = _open_capture(filename)
+    frames = []
+    if frames_start:
+        cap.set(pos_prop, frames_start)
+    frame_idx = frames_start or 0
+    while cap.isOpened():
+        if frames_end and frame_idx >= frames_end:
+            break
+        ret, frame = cap.read()
+        if not ret:
+            break
+        if grayscale and len(frame.shape) == 3:
+            frame = _to_grey(frame)
+        frames.append(frame)
+        frame_idx += 1
+    cap.release()
+    return frames
+
+
+def get_video_frames_from_url(url, local_filename="temp_video.avi", frames_start=None, frames_end=None):
+    """ip.py:137-149."""
+    download_video_from_url(url, local_filename)
+    return load_video_frames(local_filename, frames_start, frames_end)
+
+
+# ---------------------------------------------------------------------------------------------
+# settings (ip.py:154-180)
+# ---------------------------------------------------------------------------------------------
+def _prepare_settings(params):
+    """ip.py:154-180: the nine defaults, overridden by ``params``, as attributes of a class ``S``."""
+    values = dict(_hostmath.DEFAULT_SETTINGS)
+    if params:
+        values.update(params)
+    return type("S", (), values)
+
+
+def _engine_params(settings):
+    keys = ("consecutive_threshold", "brightness_threshold", "flow_threshold", "static_threshold",
+            "min_cluster_size", "max_cluster_size", "min_circularity", "sliding_window_radius")
+    return {k: getattr(settings, k) for k in keys}
+
+
+# ---------------------------------------------------------------------------------------------
+# background (ip.py:183-252)
+# ---------------------------------------------------------------------------------------------
+def compute_background(frames, index=None, radius=None):
+    """ip.py:183-200: background of frame ``index`` from the +-radius temporal window, centre excluded.
+    Newer call form ``compute_background(frames, radius=r)``: the backgrounds of all frames, stacked."""
+    if radius is None:                                  # batch form: (frames, radius) or (frames, radius=r)
+        radius = 1 if index is None else index
+        return np.stack([compute_background(frames, i, radius) for i in range(len(frames))])
+    start = max(0, index - radius)
+    end = min(len(frames), index + radius + 1)
+    window = _as_u8(np.asarray(frames[start:end]))
+    if len(window) < 2:
+        raise ValueError("the background window of a frame needs at least one neighbour")
+    with _Scoped(sliding_window_radius=max(int(radius), 1)) as eng:
+        return eng.background(eng.to_device(window), index - start).cpu().numpy()
+
+
+def _find_background(frames, pixel_std_coeff=1.0):
+    """ip.py:203-252 on a stack of neighbour frames (centre already removed): mean of the values
+    <= mean + coeff*std per pixel, float32."""
+    stack = _as_u8(frames)
+    n = len(stack)
+    if not 1 <= n <= 8:
+        raise ValueError("_find_background handles 1..8 neighbour frames on the GPU (window radius <= 8)")
+    ext = np.concatenate([stack, stack[:1]])            # dummy centre at index n; window = all n others
+    with _Scoped(sliding_window_radius=n, pixel_std_coeff=float(pixel_std_coeff)) as eng:
+        return eng.background(eng.to_device(ext), n).cpu().numpy()
+
+
+# ---------------------------------------------------------------------------------------------
+# raw mask (ip.py:255-267, 635-648)
+# ---------------------------------------------------------------------------------------------
+def get_damaged_pixel_mask(frame, *args):
+    """ip.py:635-648 -> (uint8 mask, threshold array).  Accepts ``(frame, height, width, background)``
+    (this reference) and ``(frame, background)`` (newer form)."""
+    background = args[-1]
+    eng = _engine()
+    f8 = _as_u8(frame, "frame")
+    bg = np.asarray(background)
+    if bg.dtype != np.float32:
+        bg = bg.astype(np.float64)                      # ip.py:638 follows the background's dtype
+    m, thr = eng.damaged_mask(eng.to_device(f8), eng.to_device(bg))
+    return m.cpu().numpy(), thr.cpu().numpy()
+
+
+def _raw_damaged_mask(frame, background):
+    """ip.py:255-267."""
+    mask, _ = get_damaged_pixel_mask(frame, background)
+    return np.asarray(mask).astype(bool)
+
+
+# ---------------------------------------------------------------------------------------------
+# temporal maps (ip.py:270-310, 438-481)
+# ---------------------------------------------------------------------------------------------
+def compute_persistent_mask(masks, consecutive_threshold):
+    """ip.py:270-289: pixels flagged in >= ``consecutive_threshold`` consecutive frames; ``None`` resets."""
+    H, W = np.asarray(masks[0]).shape                   # ip.py:275 (frame 0 is always kept)
+    keep, st = _stack_masks(masks, (H, W))
+    with _Scoped(consecutive_threshold=int(consecutive_threshold)) as eng:
+        p = eng.persistent_mask(_bits(eng, st), eng.to_device(keep), H, W)
+        return _unbits(eng, p, H, W)[0]
+
+
+def _suppress(masks, bad_planes):
+    """m & ~(OR of bad_planes) for every non-None mask (ipx_finalize) -> (list, counts list)."""
+    shape = next((np.asarray(m).shape for m in masks if m is not None), None)
+    if shape is None:
+        return [None] * len(masks), [np.nan] * len(masks)
+    H, W = shape
+    keep, st = _stack_masks(masks, shape)
+    eng = _engine()
+    planes = [np.asarray(b).astype(bool) for b in bad_planes]
+    pers = _bits(eng, planes[0][None])[0]
+    stat = _bits(eng, planes[1][None])[0] if len(planes) > 1 else None
+    import torch
+    dummy = torch.zeros((len(masks), H, W), dtype=torch.uint8, device=eng.device)
+    fin, counts = eng.finalize(dummy, _bits(eng, st), pers, stat, eng.to_device(keep))
+    fin = _unbits(eng, fin, H, W)
+    counts = counts.cpu().numpy()
+    out = [fin[i] if keep[i] else None for i in range(len(masks))]
+    cnt = [int(counts[i, 0]) if keep[i] else np.nan for i in range(len(masks))]
+    return out, cnt
+
+
+def filter_consecutive_pixels(masks, persistent, return_counts=True):
+    """ip.py:292-310."""
+    out, cnt = _suppress(masks, [persistent])
+    return (out, cnt) if return_counts else out
+
+
+def compute_static_mask(frames, masks, brightness_threshold, static_threshold, min_valid_frames):
+    """ip.py:438-465."""
+    fr = _as_u8(np.stack([np.asarray(f) for f in frames]))
+    H, W = fr.shape[1:]
+    keep, st = _stack_masks(masks, (H, W))
+    with _Scoped(brightness_threshold=float(brightness_threshold), static_threshold=float(static_threshold),
+                 min_valid_frames=int(min_valid_frames)) as eng:
+        zero = eng.empty_bits(1, H, W)[0].zero_()
+        maps = eng.static_maps(eng.to_device(fr), _bits(eng, st), zero, eng.to_device(keep))
+        return _unbits(eng, eng.static_from_maps(maps), H, W)[0]
+
+
+def apply_static_suppression(masks, persistent, static_mask, calc_counts=True):
+    """ip.py:468-481."""
+    out, cnt = _suppress(masks, [persistent, static_mask])
+    return (out, np.array(cnt, dtype=float)) if calc_counts else out
+
+
+# ---------------------------------------------------------------------------------------------
+# bright-area estimates and final counts (ip.py:351-365, 770-847)
+# ---------------------------------------------------------------------------------------------
+def _frame_counters(frames, masks, brightness_threshold, estimate_threshold):
+    """Per frame (keep, [sum m, #(m & f<est), #(m & f>bt), #(f<est), #(f>bt)])."""
+    fr = _as_u8(np.stack([np.asarray(f) for f in frames]))
+    n, H, W = fr.shape
+    keep, st = _stack_masks(masks, (H, W))
+    with _Scoped(brightness_threshold=float(brightness_threshold),
+                 estimate_threshold=int(math.ceil(estimate_threshold))) as eng:
+        fd = eng.to_device(fr)
+        zero = eng.empty_bits(1, H, W)[0].zero_()
+        _, c3 = eng.finalize(fd, _bits(eng, st), zero, None, None, want_bits=False)
+        d2 = eng.dense_counts(fd)
+        return keep, np.concatenate([c3.cpu().numpy(), d2.cpu().numpy()], axis=1), H * W
+
+
+def estimate_damaged_pixels_in_bright_areas(frames, damaged_pixel_masks, brightness_threshold=170):
+    """ip.py:770-821: damaged-pixel density of the dark area times the bright area, per frame."""
+    _, c, P = _frame_counters(frames, damaged_pixel_masks, brightness_threshold, brightness_threshold)
+    out = np.full(len(c), np.nan, np.float64)
+    for i, (m, m_low, _, n_low, _) in enumerate(c.tolist()):
+        low = n_low - m_low
+        high = (P - n_low) - (m - m_low)
+        if low > 0:
+            out[i] = round((m / low) * high)
+    return out
+
+
+def find_bright_area_estimates(frames, damaged_pixel_masks, brightness_threshold):
+    """ip.py:824-847 (the inner estimate uses the default 170, ip.py:836)."""
+    keep, c, P = _frame_counters(frames, damaged_pixel_masks, brightness_threshold, 170)
+    out = np.full(len(c), np.nan, np.float64)
+    for i, row in enumerate(c.tolist()):
+        if keep[i]:
+            out[i] = _hostmath.bright_area_estimate(*row, P)
+    return out
+
+
+def _get_final_count(masks, bright_estimates):
+    """ip.py:351-365."""
+    shape = next((np.asarray(m).shape for m in masks if m is not None), None)
+    if shape is None:
+        return np.array([np.nan + (e if not np.isnan(e) else 0) for e in bright_estimates], dtype=float)
+    keep, st = _stack_masks(masks, shape)
+    eng = _engine()
+    import torch
+    H, W = shape
+    dummy = torch.zeros((len(masks), H, W), dtype=torch.uint8, device=eng.device)
+    zero = eng.empty_bits(1, H, W)[0].zero_()
+    _, c3 = eng.finalize(dummy, _bits(eng, st), zero, None, None, want_bits=False)
+    sums = c3.cpu().numpy()[:, 0]
+    return np.array([(sums[i] if keep[i] else np.nan) + (e if not np.isnan(e) else 0)
+                     for i, e in enumerate(bright_estimates)], dtype=float)
+
+
+# ---------------------------------------------------------------------------------------------
+# cluster statistics (ip.py:332-348, 651-728)
+# ---------------------------------------------------------------------------------------------
+def filter_damaged_pixel_clusters(frame, damaged_pixel_mask, min_cluster_size, max_cluster_size, min_circularity,
+                                  circularity_size_threshold=10):
+    """ip.py:651-728 -> (cleaned bool mask, cluster count, mean cluster size, mean cluster brightness).
+    A structuring element passed in the 6th position (newer API) is accepted and must be the 3x3 cross."""
+    if isinstance(circularity_size_threshold, np.ndarray):
+        if not np.array_equal(circularity_size_threshold != 0, [[0, 1, 0], [1, 1, 1], [0, 1, 0]]):
+            raise ValueError("only the 3x3 cross (cv2 MORPH_ELLIPSE 3x3) is supported")
+        circularity_size_threshold = 10
+    f8 = _as_u8(frame, "frame")
+    H, W = f8.shape
+    m = np.asarray(damaged_pixel_mask).astype(bool)
+    with _Scoped(min_cluster_size=int(min_cluster_size), max_cluster_size=int(max_cluster_size),
+                 min_circularity=float(min_circularity),
+                 circularity_size_threshold=int(circularity_size_threshold)) as eng:
+        stats, cleaned = eng.cluster_stats(eng.to_device(f8[None]), _bits(eng, m[None]), want_cleaned=True)
+        c, sa, sb = stats.cpu().numpy()[0].tolist()
+        cleaned = _unbits(eng, cleaned, H, W)[0]
+    if c == 0:
+        return np.zeros((H, W), bool), 0, 0.0, float("nan")
+    return cleaned, int(c), float(sa / c), float(sb / sa)
+
+
+_ORIG = {}
+
+
+def _pristine(*names):
+    g = globals()
+    return all(g[n] is _ORIG[n] for n in names)
+
+
+def compute_cluster_stats(frames, masks, flows, settings, n_jobs=-1):
+    """ip.py:332-348 -> array of three float64 rows (cluster_count, cluster_size, cluster_brightness)."""
+    n = len(masks)
+    if not _pristine("filter_damaged_pixel_clusters"):                       # a caller replaced the stage
+        res = []
+        for frame, mask, flow in zip(frames, masks, flows):
+            if mask is None or flow > settings.flow_threshold:
+                res.append((0.0, 0.0, 0.0))
+            else:
+                _, c, s, b = filter_damaged_pixel_clusters(frame, mask, settings.min_cluster_size,
+                                                           settings.max_cluster_size, settings.min_circularity)
+                res.append((c, s, b))
+        return np.array(res).T
+    res = np.zeros((n, 3), np.float64)
+    live = [i for i in range(n) if not (masks[i] is None or flows[i] > settings.flow_threshold)]
+    if live:
+        fr = _as_u8(np.stack([np.asarray(frames[i]) for i in live]))
+        ms = np.stack([np.asarray(masks[i]).astype(bool) for i in live])
+        with _Scoped(min_cluster_size=int(settings.min_cluster_size), max_cluster_size=int(settings.max_cluster_size),
+                     min_circularity=float(settings.min_circularity)) as eng:
+            stats, _ = eng.cluster_stats(eng.to_device(fr), _bits(eng, ms))
+            stats = stats.cpu().numpy().tolist()
+        for i, (c, sa, sb) in zip(live, stats):
+            res[i] = (c, sa / c, sb / sa) if c else (0, 0.0, np.nan)
+    return res.T
+
+
+# ---------------------------------------------------------------------------------------------
+# bright-region rejection (ip.py:731-767)
+# ---------------------------------------------------------------------------------------------
+def remove_bright_regions(background, brightness_threshold, filtered_damaged_pixels, max_cluster_size):
+    """ip.py:731-767: drop damaged components that touch a bright-background blob of >= max_cluster_size px."""
+    bright = np.asarray(background) > brightness_threshold
+    dmg = np.asarray(filtered_damaged_pixels).astype(bool)
+    H, W = dmg.shape
+    with _Scoped(max_cluster_size=int(max_cluster_size)) as eng:
+        out = eng.remove_bright_regions(_bits(eng, bright[None]), _bits(eng, dmg[None]), H, W)
+        return _unbits(eng, out, H, W)[0]
+
+
+# ---------------------------------------------------------------------------------------------
+# motion test (ip.py:852-904)
+# ---------------------------------------------------------------------------------------------
+def compute_optical_flow_metric(frames):
+    """ip.py:852-873: flows[0] = 0, flows[i] = mean Farneback flow magnitude between frames i-1 and i."""
+    if len(frames) == 0:
+        return np.zeros(0)
+    fr = _as_u8(np.stack([np.asarray(f) for f in frames]))
+    eng = _engine()
+    flows, _ = eng.flow_metric(eng.to_device(fr), want_keep=False)
+    return flows.cpu().numpy().astype(np.float64)
+
+
+def filter_frames_by_optical_flow(frames, pixel_counts, optical_flows, damaged_pixel_masks, threshold,
+                                  removed_displayed=False):
+    """ip.py:876-904 (not on the detection path; plain indexing)."""
+    frames = np.asarray(frames)
+    pixel_counts = np.asarray(pixel_counts)
+    optical_flows = np.asarray(optical_flows)
+    damaged_pixel_masks = np.asarray(damaged_pixel_masks)
+    valid = optical_flows <= threshold
+    if removed_displayed:
+        print(f"Removed {len(frames) - int(valid.sum())} frames due to high optical flow")
+    return frames[valid], pixel_counts[valid], damaged_pixel_masks[valid], optical_flows[valid]
+
+
+def find_damaged_pixel_heatmap(frames, damaged_pixel_masks, brightness_threshold):
+    """ip.py:907-933: heat / valid * 100 where more than 10 frames are valid (same sums as the static map)."""
+    fr = _as_u8(np.asarray(frames))
+    H, W = fr.shape[1:]
+    ms = np.asarray(damaged_pixel_masks).astype(bool)
+    with _Scoped(brightness_threshold=float(brightness_threshold)) as eng:
+        zero = eng.empty_bits(1, H, W)[0].zero_()
+        maps = eng.static_maps(eng.to_device(fr), _bits(eng, ms), zero, None).cpu().numpy()
+    heat, valid = maps[0].astype(np.int64), maps[1].astype(np.int64)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        return np.where(valid > 10, heat / valid * 100.0, 0.0)
+
+
+# ---------------------------------------------------------------------------------------------
+# orchestration (ip.py:526-632)
+# ---------------------------------------------------------------------------------------------
+_STAGES = ("compute_optical_flow_metric", "compute_background", "_raw_damaged_mask", "get_damaged_pixel_mask",
+           "remove_bright_regions", "compute_persistent_mask", "filter_consecutive_pixels", "compute_static_mask",
+           "apply_static_suppression", "find_bright_area_estimates", "estimate_damaged_pixels_in_bright_areas",
+           "_get_final_count", "compute_cluster_stats", "filter_damaged_pixel_clusters", "_prepare_settings")
+
+
+def detect_damaged_pixels(frames, chunk_index=0, plot=False, show_plots=False, save_plots=False,
+                          output_folder="results", visualise_damaged_pixels_plot=True, plot_damaged_pixels_plot=True,
+                          plot_heatmap_plot=True, params=None):
+    """ip.py:526-632: one chunk of greyscale frames -> (total_counts, cluster_counts, avg_sizes,
+    avg_brightnesses), four float64 arrays; NaN count = frame discarded by the motion test."""
+    if not _pristine(*_STAGES):
+        return _detect_stagewise(frames, chunk_index, plot, show_plots, save_plots, output_folder,
+                                 visualise_damaged_pixels_plot, plot_damaged_pixels_plot, plot_heatmap_plot, params)
+    settings = _prepare_settings(params)
+    fr = _as_u8(np.asarray(frames))
+    with _Scoped(**_engine_params(settings)) as eng:
+        r = eng.detect_chunk(fr, want_masks=bool(plot))
+    if plot:
+        _generate_plots(fr, chunk_index, r["final_masks"], r["total_counts"], r["flows"], settings,
+                        show_plots=show_plots, save_plots=save_plots, output_folder=output_folder,
+                        visualise_damaged_pixels_plot=visualise_damaged_pixels_plot,
+                        plot_damaged_pixels_plot=plot_damaged_pixels_plot, plot_heatmap_plot=plot_heatmap_plot)
+    return r["total_counts"], r["cluster_counts"], r["avg_sizes"], r["avg_brightnesses"]
+
+
+def _detect_stagewise(frames, chunk_index, plot, show_plots, save_plots, output_folder,
+                      visualise_damaged_pixels_plot, plot_damaged_pixels_plot, plot_heatmap_plot, params):
+    """The same sequence, one module-global stage call at a time (used when a stage was replaced)."""
+    settings = _prepare_settings(params)
+    frames = np.asarray(frames)
+    optical_flows = compute_optical_flow_metric(frames)
+    raw_masks = np.full(len(frames), None, dtype=object)
+    for i, frame in enumerate(frames):
+        if optical_flows[i] <= settings.flow_threshold:
+            background = compute_background(frames, i, settings.sliding_window_radius)
+            raw_mask = _raw_damaged_mask(frame, background)
+            raw_masks[i] = remove_bright_regions(background, settings.brightness_threshold, raw_mask,
+                                                 settings.max_cluster_size)
+    persistent_pixels = compute_persistent_mask(raw_masks, settings.consecutive_threshold)
+    clean_masks, _ = filter_consecutive_pixels(raw_masks, persistent_pixels)
+    static_mask = compute_static_mask(frames, clean_masks, settings.brightness_threshold, settings.static_threshold, 10)
+    final_masks, total_counts = apply_static_suppression(clean_masks, persistent_pixels, static_mask)
+    bright_area_estimates = find_bright_area_estimates(frames, final_masks, settings.brightness_threshold)
+    total_counts = _get_final_count(final_masks, bright_area_estimates)
+    cluster_counts, avg_sizes, avg_brightnesses = compute_cluster_stats(frames, final_masks, optical_flows, settings)
+    if plot:
+        _generate_plots(frames, chunk_index, final_masks, total_counts, optical_flows, settings,
+                        show_plots=show_plots, save_plots=save_plots, output_folder=output_folder,
+                        visualise_damaged_pixels_plot=visualise_damaged_pixels_plot,
+                        plot_damaged_pixels_plot=plot_damaged_pixels_plot, plot_heatmap_plot=plot_heatmap_plot)
+    return total_counts, cluster_counts, avg_sizes, avg_brightnesses
+
+
+# ---------------------------------------------------------------------------------------------
+# plots (ip.py:381-435, 936-1065, 1096-1133) -- presentation only, matplotlib optional
+# ---------------------------------------------------------------------------------------------
+def _generate_plots(frames, chunk_index, masks, counts, flows, settings, show_plots=True, save_plots=False,
+                    output_folder="results", visualise_damaged_pixels_plot=True, plot_damaged_pixels_plot=True,
+                    plot_heatmap_plot=True):
+    """ip.py:381-435."""
+    if visualise_damaged_pixels_plot:
+        survivors = [i for i, flow in enumerate(flows) if flow <= settings.flow_threshold]
+        for i in survivors[:settings.number_of_plots]:
+            visualise_damaged_pixels(frames[i], i, chunk_index, masks[i], counts[i], show_plots=show_plots,
+                                     save_plots=save_plots, output_folder=output_folder)
+    if plot_damaged_pixels_plot:
+        plot_damaged_pixels(counts, chunk_index, show_plots=show_plots, save_plots=save_plots,
+                            output_folder=output_folder)
+    if plot_heatmap_plot:
+        shape = np.asarray(frames[0]).shape
+        heatmap = find_damaged_pixel_heatmap(
+            frames, [np.asarray(m).astype(bool) if m is not None else np.zeros(shape, bool) for m in masks],
+            settings.brightness_threshold)
+        plot_heatmap(heatmap, chunk_index, show_plots=show_plots, save_plots=save_plots, output_folder=output_folder)
+
+
+def _blend(base, overlay):
+    """cv2.addWeighted(base, 0.8, overlay, 1.0, 0) for uint8 images."""
+    return np.clip(np.rint(base.astype(np.float64) * 0.8 + overlay.astype(np.float64)), 0, 255).astype(np.uint8)
+
+
+def visualise_damaged_pixels(frame, frame_index, chunk_index, cluster_mask, cluster_count, bright_threshold=170,
+                             show_plots=True, save_plots=False, output_folder="results"):
+    """ip.py:936-1002: the frame next to a copy with damaged pixels and bright areas overlaid."""
+    if not HAS_MATPLOTLIB:
+        print("matplotlib not available - skipping damaged pixel visualisation")
+        return
+    frame = np.asarray(frame)
+    vis = np.repeat(frame[:, :, None], 3, axis=2)                       # grey -> BGR
+    over = np.zeros_like(vis)
+    if cluster_mask is not None:
+        over[np.asarray(cluster_mask).astype(bool)] = (0, 165, 255)
+    vis = _blend(vis, over)
+    over = np.zeros_like(vis)
+    over[frame > bright_threshold] = (255, 0, 0)
+    vis = _blend(vis, over)
+    plt.figure(figsize=(14, 6))
+    plt.subplot(1, 2, 1)
+    plt.imshow(frame, cmap="gray", vmin=0, vmax=255)
+    plt.title(f"original chunk {chunk_index}, frame {frame_index}")
+    plt.axis("off")
+    plt.subplot(1, 2, 2)
+    plt.imshow(vis[:, :, ::-1])                                         # BGR -> RGB
+    plt.title(f"clusters: {cluster_count}")
+    plt.axis("off")
+    plt.legend(handles=[mpatches.Patch(color="orange", label="Damaged Pixels"),
+                        mpatches.Patch(color="royalblue", label="Bright Background Areas")],
+               loc="upper left", fontsize="small", frameon=True)
+    if show_plots:
+        plt.show()
+    if save_plots:
+        plt.tight_layout()
+        os.makedirs(output_folder, exist_ok=True)
+        plt.savefig(os.path.join(output_folder,
+                                 f"visualise_damaged_pixels_frame_{chunk_index=}_{frame_index=}.png"), dpi=300)
+    plt.close()
+
+
+def plot_heatmap(heatmap, chunk_index, title="Damaged Pixel Heatmap", show_plots=True, save_plots=False,
+                 output_folder="results", figsize=(15, 10)):
+    """ip.py:1005-1032."""
+    if not HAS_MATPLOTLIB:
+        print("matplotlib not available - skipping heatmap plot")
+        return
+    plt.figure(figsize=figsize)
+    plt.imshow(heatmap, cmap="viridis", interpolation="nearest")
+    plt.colorbar(label="Percentage of frames (%)")
+    plt.title(f"{title} ({chunk_index = })")
+    if show_plots:
+        plt.show()
+    if save_plots:
+        plt.tight_layout()
+        os.makedirs(output_folder, exist_ok=True)
+        plt.savefig(os.path.join(output_folder, f"{title.lower().replace(' ', '_')}_{chunk_index=}.png"), dpi=300)
+    plt.close()
+
+
+def plot_damaged_pixels(damaged_pixel_counts, chunk_index, show_plots=True, save_plots=False, output_folder="results"):
+    """ip.py:1035-1065."""
+    if not HAS_MATPLOTLIB:
+        print("matplotlib not available - skipping damaged pixel output graph")
+        return
+    plt.figure(figsize=(10, 5))
+    plt.plot(damaged_pixel_counts, label="Damaged Pixels Count", color="blue")
+    plt.xlabel("Frame Number")
+    plt.ylabel("Number of Damaged Pixels")
+    plt.title(f"Damaged Pixels Detected Over Time ({chunk_index = })")
+    plt.legend()
+    if show_plots:
+        plt.show()
+    if save_plots:
+        plt.tight_layout()
+        os.makedirs(output_folder, exist_ok=True)
+        plt.savefig(os.path.join(output_folder, f"plot_damged_pixels_{chunk_index=}.png"), dpi=300)
+    plt.close()
+
+
+def chunked_nanmean(array, step):
+    """ip.py:1068-1085: nan-means over windows of ``step`` samples, the last window may be partial."""
+    if len(array) == 0:
+        return [np.nan]
+    array = np.asarray(array)
+    n_full = (len(array) // step) * step
+    means = np.nanmean(array[:n_full].reshape(-1, step), axis=1)
+    remainder = len(array) % step
+    if remainder > 0:
+        means = np.append(means, np.nanmean(array[-remainder:]))
+    return means.tolist()
+
+
+def plot_all_chunks(all_counts, all_clusters, all_sizes, all_brightness, times, show_plots=True, save_plots=False,
+                    output_folder="results"):
+    """ip.py:1096-1133."""
+    if not HAS_MATPLOTLIB:
+        print("matplotlib not available - skipping combined chunk plot")
+        return
+    fig, axes = plt.subplots(4, 1, figsize=(12, 10), sharex=True)
+    for ax, series, colour, label in zip(axes, (all_counts, all_clusters, all_sizes, all_brightness),
+                                         ("blue", "orange", "green", "red"),
+                                         ("Damaged Pixel Count", "Cluster Count", "Average Cluster Size",
+                                          "Average Brightness")):
+        ax.plot(series, color=colour, label=label)
+        ax.legend(loc="upper right")
+        ax.grid(True, linestyle="--", alpha=0.5)
+    axes[0].set_title("Combined Chunk Results Over Frames")
+    axes[-1].set_xlabel("Frame Index" if times is None else "Time (s)")
+    if times is not None:
+        for ax in axes:
+            ax.set_xlim([0, len(times)])
+    plt.tight_layout()
+    if save_plots:
+        os.makedirs(output_folder, exist_ok=True)
+        plt.savefig(os.path.join(output_folder, "combined_chunks_overview.png"), dpi=300)
+    if show_plots:
+        plt.show()
+    plt.close()
+
+
+# ---------------------------------------------------------------------------------------------
+# chunk driver and CLI (ip.py:1136-1350)
+# ---------------------------------------------------------------------------------------------
+def _video_info(video_filename):
+    cap, _ = _open_capture(video_filename)
+    if cv2 is not None:
+        n, fps = int(cap.get(cv2.CAP_PROP_FRAME_COUNT)), cap.get(cv2.CAP_PROP_FPS)
+    else:
+        n, fps = int(cap.get(_avi.VideoCapture.CAP_PROP_FRAME_COUNT)), cap.get(_avi.VideoCapture.CAP_PROP_FPS)
+    cap.release()
+    return n, fps
+
+
+def main(video_filename, average_time=1.0, max_chunks=None, step_size=1000, plot=False, show_plots=False,
+         save_plots=False, output_folder="results", visualise_damaged_pixels_plot=True, plot_damaged_pixels_plot=True,
+         plot_heatmap_plot=True, params=None):
+    """ip.py:1136-1247: process a video in chunks of ``step_size`` frames and return the per-window
+    averages (``average_time`` seconds each) of the four per-frame series, plus the window mid-times."""
+    num_frames, FPS = _video_info(video_filename)
+    edges = np.arange(0, num_frames, step_size)
+    if edges[-1] != num_frames:
+        edges = np.concatenate([edges, [num_frames]])
+    if max_chunks is not None:
+        edges = edges[:max_chunks + 1]
+    per_chunk = ([], [], [], [])
+    step = int(round(FPS * average_time))
+    for idx in range(len(edges) - 1):
+        start, end = edges[idx], edges[idx + 1]
+        print(f"processing chunk {idx}: frames {start}–{end}")
+        chunk = load_video_frames(video_filename, frames_start=start, frames_end=end)
+        res = detect_damaged_pixels(chunk, idx, plot=plot, show_plots=show_plots, save_plots=save_plots,
+                                    output_folder=output_folder,
+                                    visualise_damaged_pixels_plot=visualise_damaged_pixels_plot,
+                                    plot_damaged_pixels_plot=plot_damaged_pixels_plot,
+                                    plot_heatmap_plot=plot_heatmap_plot, params=params)
+        for store, series in zip(per_chunk, res):
+            store.append(series)
+    counts, clusters, sizes, brightness = (np.concatenate(s) for s in per_chunk)
+    averages_counts = chunked_nanmean(counts, step)
+    times = ((np.arange(len(averages_counts)) * step) + step / 2) / FPS
+    return {
+        "averages_counts": averages_counts,
+        "averages_clusters": chunked_nanmean(clusters, step),
+        "averages_size": chunked_nanmean(sizes, step),
+        "averages_brightness": chunked_nanmean(brightness, step),
+        "times": times,
+    }
+
+
+for _n in _STAGES:
+    _ORIG[_n] = globals()[_n]
+del _n
+
+
+def _cli(argv=None):
+    """The reference's command line (ip.py:1250-1350): same flags, every value a string."""
+    import argparse
+    parser = argparse.ArgumentParser()
+    parser.add_argument("-vf", "--video_filename", help="Path to the AVI file")
+    parser.add_argument("-at", "--average_time", help="How many seconds to average over in the final summaries")
+    parser.add_argument("-mc", "--max_chunks", help="If not None, only process that many chunks (for quick tests)")
+    parser.add_argument("-ss", "--step_size", help="The number of frames in each chunk")
+    parser.add_argument("-shp", "--show_plots", help="(Default=False) True or False: show plots")
+    parser.add_argument("-svp", "--save_plots", help="(Default=False) True or False: save plots")
+    parser.add_argument("-vdpp", "--visualise_damaged_pixels_plot", help="(Default=False) True or False")
+    parser.add_argument("-pdpp", "--plot_damaged_pixels_plot", help="(Default=True) True or False")
+    parser.add_argument("-php", "--plot_heatmap_plot", help="(Default=True) True or False")
+    parser.add_argument("-cp", "--chunk_plots", help="(Default=True) True or False: per-chunk plots")
+    parser.add_argument("-ap", "--average_plots", help="(Default=True) True or False: final averages plot")
+    parser.add_argument("-of", "--output_folder", help="Location of where saved plots are saved")
+    for short, name in (("-ct", "consecutive_threshold"), ("-bt", "brightness_threshold"), ("-ft", "flow_threshold"),
+                        ("-st", "static_threshold"), ("-mncs", "min_cluster_size"), ("-mxcs", "max_cluster_size"),
+                        ("-mnc", "min_circularity"), ("-swr", "sliding_window_radius"), ("-np", "number_of_plots")):
+        parser.add_argument(short, "--" + name)
+    args = parser.parse_args(argv)
+
+    def flag(v, default):
+        return (v.lower() == "true") if v else default
+
+    def num(v, cast, default):
+        return cast(v) if v else default
+
+    if args.max_chunks:
+        max_chunks = None if args.max_chunks.lower() == "none" else int(args.max_chunks)
+    else:
+        max_chunks = 2                                                  # ip.py:1293
+    show_plots, save_plots = flag(args.show_plots, False), flag(args.save_plots, False)
+    plot = (show_plots or save_plots) and flag(args.chunk_plots, True)
+    output_folder = args.output_folder if args.output_folder else "results"
+    params = {
+        "consecutive_threshold": num(args.consecutive_threshold, int, 2),
+        "brightness_threshold": num(args.brightness_threshold, int, 170),
+        "flow_threshold": num(args.flow_threshold, float, 2.0),
+        "static_threshold": num(args.static_threshold, int, 50),
+        "min_cluster_size": num(args.min_cluster_size, int, 5),
+        "max_cluster_size": num(args.max_cluster_size, int, 20),
+        "min_circularity": num(args.min_circularity, float, 0.1),
+        "sliding_window_radius": num(args.sliding_window_radius, int, 3),
+        "number_of_plots": num(args.number_of_plots, int, 20),
+    }
+    results = main(
+        args.video_filename if args.video_filename else "11_01_H_170726081325.avi",
+        average_time=num(args.average_time, float, 1.0), max_chunks=max_chunks,
+        step_size=num(args.step_size, int, 1000), plot=plot, show_plots=show_plots, save_plots=save_plots,
+        output_folder=output_folder,
+        visualise_damaged_pixels_plot=flag(args.visualise_damaged_pixels_plot, False),
+        plot_damaged_pixels_plot=flag(args.plot_damaged_pixels_plot, True),
+        plot_heatmap_plot=flag(args.plot_heatmap_plot, True), params=params)
+    if flag(args.average_plots, True) and HAS_MATPLOTLIB:
+        plot_all_chunks(results["averages_counts"], results["averages_clusters"], results["averages_size"],
+                        results["averages_brightness"], results["times"], show_plots=show_plots,
+                        save_plots=save_plots, output_folder=output_folder)
+    else:
+        print("counts:", results["averages_counts"])
+        print("clusters:", results["averages_clusters"])
+        print("sizes:", results["averages_size"])
+        print("brightness:", results["averages_brightness"])
+        print("times:", results["times"])
+    print("\nDone")
+    return results
+
+
+if __name__ == "__main__":
+    _cli()

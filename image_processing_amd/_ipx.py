@@ -77,6 +77,7 @@ PROTOTYPES = {
     "ipx_static_maps": (_i, [_ctx, _p, _p, _p, _p, _i, _i, _i, _p, _p]),
     "ipx_static_from_maps": (_i, [_ctx, _p, _p, _i, _i, _p]),
     "ipx_finalize": (_i, [_ctx, _p, _p, _p, _p, _p, _i, _i, _i, _p, _p]),
+    "ipx_dense_counts": (_i, [_ctx, _p, _i, _i, _i, _p]),
     "ipx_cluster_stats": (_i, [_ctx, _p, _p, _p, _i, _i, _i, _p, _i, _p, _p]),
     "ipx_detect_chunk": (_i, [_ctx, _p, _i, _i, _i, _p, _i, _p, _p, _p, _p, _p]),
     "ipx_pack_mask": (_i, [_ctx, _p, _i, _i, _i, _p]),

@@ -1,0 +1,184 @@
+"""Uncompressed AVI (RIFF) reader / writer for 8-bit greyscale and 24-bit BGR footage.
+
+The reference decodes through cv2.VideoCapture (ip.py:62-85); cv2 is optional here.  This module
+is the cv2-free input side used by the benchmarks and tests: ``write_avi`` stores frames as raw DIBs
+(8-bit palettised grey or 24-bit BGR, bottom-up rows padded to 4 bytes -- what FFmpeg's rawvideo
+decoder and therefore cv2 read back byte-exactly), ``AviReader`` memory-maps such a file and
+returns frames by index without copying the file.  Compressed streams (MJPG, ...) are refused:
+decode them with cv2.
+"""
+import mmap
+import os
+import struct
+
+import numpy as np
+
+
+def _chunk(fourcc, payload):
+    pad = b"\0" if len(payload) & 1 else b""
+    return fourcc + struct.pack("<I", len(payload)) + payload + pad
+
+
+def _list(kind, payload):
+    return _chunk(b"LIST", kind + payload)
+
+
+def write_avi(filename, frames, fps=25.0):
+    """frames: iterable of (H,W) uint8 (grey) or (H,W,3) uint8 (BGR) arrays, all of one shape."""
+    frames = [np.ascontiguousarray(f, dtype=np.uint8) for f in frames]
+    if not frames:
+        raise ValueError("no frames")
+    h, w = frames[0].shape[:2]
+    colour = frames[0].ndim == 3
+    bpp = 24 if colour else 8
+    stride = (w * (3 if colour else 1) + 3) & ~3
+    img_bytes = stride * h
+    n = len(frames)
+    usec = int(round(1e6 / fps))
+    rate, scale = int(round(fps * 1000)), 1000
+    avih = struct.pack("<14I", usec, img_bytes * int(round(fps)), 0, 0x10, n, 0, 1, img_bytes, w, h, 0, 0, 0, 0)
+    strh = b"vids" + b"DIB " + struct.pack("<IHHIIIIIIII4H", 0, 0, 0, 0, scale, rate, 0, n, img_bytes, 0xFFFFFFFF, 0,
+                                           0, 0, w, h)
+    ncol = 0 if colour else 256
+    bih = struct.pack("<IiiHHIIiiII", 40, w, h, 1, bpp, 0, img_bytes, 0, 0, ncol, 0)
+    pal = b"" if colour else b"".join(struct.pack("<4B", i, i, i, 0) for i in range(256))
+    hdrl = _list(b"hdrl", _chunk(b"avih", avih) + _list(b"strl", _chunk(b"strh", strh) + _chunk(b"strf", bih + pal)))
+    movi_parts, index, off = [], [], 4
+    row = np.zeros((h, stride), np.uint8)
+    for f in frames:
+        if f.shape[:2] != (h, w) or (f.ndim == 3) != colour:
+            raise ValueError("all frames must have one shape")
+        row[:, :w * (3 if colour else 1)] = f.reshape(h, -1)
+        data = row[::-1].tobytes()                          # DIB rows are stored bottom-up
+        movi_parts.append(_chunk(b"00db", data))
+        index.append(struct.pack("<4sIII", b"00db", 0x10, off, len(data)))
+        off += 8 + len(data) + (len(data) & 1)
+    movi = _list(b"movi", b"".join(movi_parts))
+    idx1 = _chunk(b"idx1", b"".join(index))
+    body = b"AVI " + hdrl + movi + idx1
+    with open(filename, "wb") as fh:
+        fh.write(b"RIFF" + struct.pack("<I", len(body)) + body)
+    return filename
+
+
+class AviReader:
+    """Random access to the frames of an uncompressed AVI.  ``read(i)`` returns (H,W) uint8 for 8-bit
+    streams and (H,W,3) BGR uint8 for 24-bit streams."""
+
+    def __init__(self, filename):
+        self.filename = filename
+        self._fh = open(filename, "rb")
+        size = os.fstat(self._fh.fileno()).st_size
+        if size < 12:
+            raise ValueError("%s: not an AVI file" % filename)
+        self._mm = mmap.mmap(self._fh.fileno(), 0, access=mmap.ACCESS_READ)
+        mm = self._mm
+        if mm[0:4] != b"RIFF" or mm[8:12] != b"AVI ":
+            raise ValueError("%s: not a RIFF AVI file" % filename)
+        self.fps = 0.0
+        self.width = self.height = self.bpp = 0
+        self._frames = []                                   # (offset, length)
+        self._walk(12, min(size, 8 + struct.unpack("<I", mm[4:8])[0]))
+        if not self.bpp:
+            raise ValueError("%s: no video stream format found" % filename)
+        self._stride = (self.width * self.bpp // 8 + 3) & ~3
+
+    def _walk(self, pos, end):
+        mm = self._mm
+        while pos + 8 <= end:
+            cc, ln = mm[pos:pos + 4], struct.unpack("<I", mm[pos + 4:pos + 8])[0]
+            body = pos + 8
+            if cc == b"LIST":
+                kind = mm[body:body + 4]
+                if kind in (b"hdrl", b"strl", b"movi"):
+                    self._walk(body + 4, min(end, body + ln))
+            elif cc == b"avih":
+                usec = struct.unpack("<I", mm[body:body + 4])[0]
+                if usec and not self.fps:
+                    self.fps = 1e6 / usec
+            elif cc == b"strh" and mm[body:body + 4] == b"vids":
+                scale, rate = struct.unpack("<II", mm[body + 20:body + 28])
+                if scale:
+                    self.fps = rate / scale
+            elif cc == b"strf" and not self.bpp:
+                _, w, h, _, bpp, comp = struct.unpack("<IiiHHI", mm[body:body + 20])
+                if comp != 0 or bpp not in (8, 24):
+                    raise ValueError("%s: only uncompressed 8/24-bit AVI is read here (compression %r, %d bpp); "
+                                     "decode other streams with cv2" % (self.filename, mm[body + 16:body + 20], bpp))
+                self.width, self.height, self.bpp = w, abs(h), bpp
+                self._bottom_up = h > 0
+            elif cc[2:4] in (b"db", b"dc") and cc[0:2].isdigit():
+                self._frames.append((body, ln))
+            pos = body + ln + (ln & 1)
+
+    @property
+    def frame_count(self):
+        return len(self._frames)
+
+    def read(self, i):
+        off, ln = self._frames[i]
+        h, w = self.height, self.width
+        if ln < self._stride * h:
+            raise ValueError("frame %d is truncated" % i)
+        a = np.frombuffer(self._mm, dtype=np.uint8, count=self._stride * h, offset=off).reshape(h, self._stride)
+        if self._bottom_up:
+            a = a[::-1]
+        if self.bpp == 8:
+            return np.ascontiguousarray(a[:, :w])
+        return np.ascontiguousarray(a[:, :3 * w].reshape(h, w, 3))
+
+    def close(self):
+        if self._mm is not None:
+            try:
+                self._mm.close()
+            except BufferError:
+                pass
+            self._mm = None
+            self._fh.close()
+
+
+class VideoCapture:
+    """The subset of cv2.VideoCapture the detection module uses (ip.py:62-84, 1180-1183), over AviReader.
+    8-bit streams are returned as grey-coded BGR, as cv2 does."""
+    CAP_PROP_POS_FRAMES, CAP_PROP_FPS, CAP_PROP_FRAME_COUNT = 1, 5, 7
+
+    def __init__(self, filename):
+        self._pos = 0
+        try:
+            self._r = AviReader(filename)
+        except (OSError, ValueError):
+            self._r = None
+
+    def isOpened(self):
+        return self._r is not None
+
+    def set(self, prop, value):
+        if prop == self.CAP_PROP_POS_FRAMES:
+            self._pos = int(value)
+            return True
+        return False
+
+    def get(self, prop):
+        if self._r is None:
+            return 0.0
+        if prop == self.CAP_PROP_FRAME_COUNT:
+            return float(self._r.frame_count)
+        if prop == self.CAP_PROP_FPS:
+            return float(self._r.fps)
+        if prop == self.CAP_PROP_POS_FRAMES:
+            return float(self._pos)
+        return 0.0
+
+    def read(self):
+        if self._r is None or self._pos >= self._r.frame_count:
+            return False, None
+        f = self._r.read(self._pos)
+        self._pos += 1
+        if f.ndim == 2:
+            f = np.repeat(f[:, :, None], 3, axis=2)
+        return True, f
+
+    def release(self):
+        if self._r is not None:
+            self._r.close()
+            self._r = None

@@ -167,7 +167,43 @@ __global__ void finalize_kernel(const uint8_t *frames, const uint64_t *raw, cons
     }
 }
 
+// per-frame {#(frame < est_lt), #(frame > frame_gt)}: the mask-independent inputs of ip.py:800-805, :840
+__global__ __launch_bounds__(256) void dense_counts_kernel(const uint8_t *frames, size_t P, int est_lt, int frame_gt,
+                                                          unsigned long long *counts)
+{
+    const uint8_t *f = frames + (size_t)blockIdx.y * P;
+    unsigned c0 = 0, c1 = 0;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < P; i += (size_t)gridDim.x * 256) {
+        const int v = f[i];
+        c0 += v < est_lt;
+        c1 += v > frame_gt;
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        c0 += __shfl_down(c0, off);
+        c1 += __shfl_down(c1, off);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(counts + (size_t)blockIdx.y * 2 + 0, (unsigned long long)c0);
+        atomicAdd(counts + (size_t)blockIdx.y * 2 + 1, (unsigned long long)c1);
+    }
+}
+
 }  // namespace
+
+extern "C" int ipx_dense_counts(ipx_ctx *ctx, const uint8_t *frames, int n, int H, int W, int64_t *counts)
+{
+    IPX_REQUIRE(ctx && frames && counts, "null pointer");
+    IPX_REQUIRE(n > 0 && n <= 65535 && H > 0 && W > 0, "bad sizes (n <= 65535 frames per call)");
+    if (int e = ipx_ctx_enter(ctx)) return e;
+    const ipx_derived d = ipx_derive(ctx->p);
+    const size_t P = (size_t)H * W;
+    IPX_CHECK_HIP(hipMemsetAsync(counts, 0, sizeof(int64_t) * 2 * (size_t)n, ctx->stream));
+    const unsigned bx = (unsigned)((P + 256 * 16 - 1) / (256 * 16));
+    IPX_LAUNCH(ctx, KID_MISC, (double)n * P, dense_counts_kernel, dim3(bx < 1 ? 1 : bx, n), dim3(256), frames, P, d.est_lt,
+               d.frame_gt, (unsigned long long *)counts);
+    IPX_LAUNCH_CHECK();
+    return IPX_OK;
+}
 
 extern "C" int ipx_persistent_mask(ipx_ctx *ctx, const uint64_t *raw_bits, const uint8_t *keep, int n, int H, int W,
                                    uint64_t *persistent_bits)

@@ -30,6 +30,7 @@ class Engine:
         self.params = _ipx.default_params()
         self._pow2 = None
         self._pow2_dim = 0
+        self._pow2_cache = {}
         self.set_params(params)
 
     def close(self):
@@ -57,9 +58,11 @@ class Engine:
             setattr(p, k, v)
         self.params = p
         check(lib.ipx_set_params(self._ctx, C.byref(p)))
-        tab, dim = hostmath.pow2_table(p.max_cluster_size)
-        self._pow2 = torch.from_numpy(tab).to(self.device)
-        self._pow2_dim = dim
+        key = int(p.max_cluster_size)
+        if key not in self._pow2_cache:
+            tab, dim = hostmath.pow2_table(key)
+            self._pow2_cache[key] = (torch.from_numpy(tab).to(self.device), dim)
+        self._pow2, self._pow2_dim = self._pow2_cache[key]
 
     # ---- plumbing --------------------------------------------------------------------------------
     def _enter(self):
@@ -205,6 +208,13 @@ class Engine:
         check(lib.ipx_finalize(self._ctx, _ptr(frames), _ptr(raw_bits), _ptr(pers_bits), _ptr(static_bits), _ptr(keep),
                                n, H, W, _ptr(fin), _ptr(counts)))
         return fin, counts
+
+    def dense_counts(self, frames):
+        n, H, W = self._chk_frames(frames)
+        counts = torch.empty((n, 2), dtype=torch.int64, device=self.device)
+        self._enter()
+        check(lib.ipx_dense_counts(self._ctx, _ptr(frames), n, H, W, _ptr(counts)))
+        return counts
 
     def cluster_stats(self, frames, mask_bits, keep=None, want_cleaned=False):
         n, H, W = self._chk_frames(frames)

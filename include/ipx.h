@@ -156,6 +156,11 @@ int ipx_finalize(ipx_ctx *ctx, const uint8_t *frames, const uint64_t *raw_bits,
                  const uint64_t *persistent_bits, const uint64_t *static_bits, const uint8_t *keep,
                  int n, int H, int W, uint64_t *final_bits, int64_t *counts);
 
+/* ---- a13/a14, mask-independent part: counts int64 [n][2] = { #(frame < estimate_threshold),
+ * #(frame > brightness_threshold) } (ip.py:800-805, :840); ipx_detect_raw produces the same
+ * numbers as a by-product for the fused path. */
+int ipx_dense_counts(ipx_ctx *ctx, const uint8_t *frames, int n, int H, int W, int64_t *counts);
+
 /* ---- a16/a17: compute_cluster_stats / filter_damaged_pixel_clusters, ip.py:332-348, 651-728 --
  * Per frame with keep != 0: morphological close (3x3 cross), 8-connected components, size
  * filter, circularity filter via the outer-contour perimeter; stats: int64 [n][3] =

@@ -1,0 +1,103 @@
+"""CPU-only checks of the boundary: libipx.so loads and exports every function include/ipx.h
+declares (no compute call is made), the ctypes table covers the header, the params struct has the
+header's layout and defaults, and the host float glue reproduces the reference's numbers."""
+import ctypes as C
+import math
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    src = open(os.path.join(ROOT, "include", "ipx.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(ipx_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    from image_processing_amd import _ipx
+    names = _declared()
+    assert len(names) >= 30
+    for n in names:
+        assert hasattr(_ipx.lib, n), "libipx.so does not export %s" % n
+    assert sorted(_ipx.PROTOTYPES) == names, "ctypes table and include/ipx.h differ"
+
+
+def test_version_error_string_and_defaults():
+    from image_processing_amd import _ipx
+    assert _ipx.lib.ipx_version() >= 100
+    assert _ipx.lib.ipx_words_per_row(1) == 1 and _ipx.lib.ipx_words_per_row(64) == 1
+    assert _ipx.lib.ipx_words_per_row(65) == 2 and _ipx.lib.ipx_words_per_row(1920) == 30
+    p = _ipx.default_params()                              # ip.py:167-177 and the hard-coded constants
+    assert (p.consecutive_threshold, p.sliding_window_radius, p.min_cluster_size, p.max_cluster_size) == (2, 3, 5, 20)
+    assert (p.min_valid_frames, p.circularity_size_threshold, p.estimate_threshold) == (10, 10, 170)
+    assert (p.brightness_threshold, p.flow_threshold, p.static_threshold, p.min_circularity, p.pixel_std_coeff) == \
+        (170.0, 2.0, 50.0, 0.1, 1.0)
+    assert C.sizeof(_ipx.Params) == 8 * 4 + 5 * 8
+    # argument errors are reported through the status code + message, without touching a GPU
+    assert _ipx.lib.ipx_device_count(None) == -1
+    assert b"null pointer" in _ipx.lib.ipx_last_error()
+
+
+def test_engine_fails_loudly_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    from image_processing_amd.engine import Engine
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        Engine(0)
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "image_processing_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", text, flags=re.M), f
+    for f in ("image_processing.py",):
+        path = os.path.join(ROOT, f)
+        if os.path.exists(path):
+            assert not re.search(r"^\s*(from|import)\s+oracle\b", open(path).read(), flags=re.M)
+
+
+def test_bright_area_estimate_matches_oracle_formula():
+    from image_processing_amd import hostmath
+    from oracle import stages as S
+    rng = np.random.default_rng(0)
+    for _ in range(200):
+        h, w = 9, 11
+        frame = rng.integers(120, 256, (h, w)).astype(np.uint8)
+        mask = rng.random((h, w)) < 0.2
+        bt = int(rng.choice([100, 170, 254]))
+        exp = S.find_bright_area_estimates([frame.astype(np.float64)], [mask], bt)[0]
+        got = hostmath.bright_area_estimate(int(mask.sum()), int((mask & (frame < 170)).sum()),
+                                            int((mask & (frame > bt)).sum()), int((frame < 170).sum()),
+                                            int((frame > bt).sum()), h * w)
+        assert (math.isnan(got) and math.isnan(exp)) or got == exp
+    # Python round: half to even
+    assert hostmath.bright_area_estimate(1, 1, 0, 3, 5, 8) == round(1 / 2 * 5)
+
+
+def test_chunk_results_nan_rules():
+    from image_processing_amd import hostmath
+    keep = np.array([1, 0, 1], np.uint8)
+    counts = np.array([[3, 3, 0, 50, 0], [0, 0, 0, 0, 0], [0, 0, 0, 64, 0]], np.int64)
+    cluster = np.array([[2, 11, 1234], [0, 0, 0], [0, 0, 0]], np.int64)
+    total, cc, cs, cb = hostmath.chunk_results(keep, counts, cluster, 64)
+    assert total[0] == 3 and np.isnan(total[1]) and total[2] == 0          # ip.py:359-362
+    assert cc.tolist() == [2, 0, 0] and cs[0] == 5.5 and cb[0] == 1234 / 11
+    assert cs[1] == 0 and cb[1] == 0                                       # discarded: zeros, ip.py:335
+    assert cs[2] == 0 and np.isnan(cb[2])                                  # kept, no cluster: nan, ip.py:680
+
+
+def test_pow2_table_is_python_pow():
+    from image_processing_amd import hostmath
+    tab, dim = hostmath.pow2_table(20)
+    assert dim >= 48 and tab.shape == (dim * dim,)
+    for a, d in [(0, 0), (3, 7), (10, 4), (20, 20)]:
+        assert tab[a * dim + d] == (a * 1.0 + d * hostmath.SQRT2_F32) ** 2

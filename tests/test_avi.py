@@ -1,0 +1,45 @@
+"""Uncompressed-AVI writer / reader round trip (the cv2-free input side), CPU only."""
+import numpy as np
+import pytest
+
+from image_processing_amd import avi
+
+
+@pytest.mark.parametrize("shape", [(6, 8), (5, 7), (9, 13, 3), (4, 6, 3)])
+def test_roundtrip(tmp_path, shape):
+    rng = np.random.default_rng(0)
+    frames = [rng.integers(0, 256, shape).astype(np.uint8) for _ in range(5)]
+    fn = str(tmp_path / "v.avi")
+    avi.write_avi(fn, frames, fps=30.0)
+    r = avi.AviReader(fn)
+    assert r.frame_count == 5 and r.fps == pytest.approx(30.0)
+    assert (r.height, r.width) == shape[:2]
+    for i in (4, 0, 2):
+        assert np.array_equal(r.read(i), frames[i])
+    r.close()
+
+
+def test_videocapture_subset(tmp_path):
+    frames = [np.full((4, 6), i, np.uint8) for i in range(7)]
+    fn = str(tmp_path / "v.avi")
+    avi.write_avi(fn, frames, fps=25)
+    cap = avi.VideoCapture(fn)
+    assert cap.isOpened() and cap.get(cap.CAP_PROP_FRAME_COUNT) == 7 and cap.get(cap.CAP_PROP_FPS) == 25
+    cap.set(cap.CAP_PROP_POS_FRAMES, 5)
+    ok, f = cap.read()
+    assert ok and f.shape == (4, 6, 3) and (f == 5).all()          # grey-coded BGR, as cv2 returns it
+    assert cap.read()[0] and not cap.read()[0]
+    cap.release()
+    bad = avi.VideoCapture(str(tmp_path / "missing.avi"))
+    assert not bad.isOpened() and bad.read() == (False, None)
+
+
+def test_rejects_compressed(tmp_path):
+    fn = str(tmp_path / "v.avi")
+    avi.write_avi(fn, [np.zeros((4, 4), np.uint8)])
+    data = bytearray(open(fn, "rb").read())
+    i = data.find(b"strf") + 8 + 16
+    data[i:i + 4] = b"MJPG"
+    open(fn, "wb").write(bytes(data))
+    with pytest.raises(ValueError, match="uncompressed"):
+        avi.AviReader(fn)
