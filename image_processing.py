@@ -183,8 +183,8 @@ def _engine_params(settings):
 def compute_background(frames, index=None, radius=None):
     """ip.py:183-200: background of frame ``index`` from the +-radius temporal window, centre excluded.
     Newer call form ``compute_background(frames, radius=r)``: the backgrounds of all frames, stacked."""
-    if radius is None:                                  # batch form: (frames, radius) or (frames, radius=r)
-        radius = 1 if index is None else index
+    if radius is None or index is None:                 # batch form: (frames, radius) or (frames, radius=r)
+        radius = radius if radius is not None else (1 if index is None else index)
         return np.stack([compute_background(frames, i, radius) for i in range(len(frames))])
     start = max(0, index - radius)
     end = min(len(frames), index + radius + 1)
