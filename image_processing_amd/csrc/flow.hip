@@ -322,17 +322,13 @@ __global__ void flow_upsample_kernel(const float2 *src, int sh, int sw, float2 *
     dst[(p * dh + dy) * (size_t)dw + dx] = o;
 }
 
-// FarnebackUpdateMatrices: pair p uses the expansions of launch frames p (R0) and p+1 (R1).
-__global__ __launch_bounds__(256) void update_matrices_kernel(const float *R, const float2 *flow, int h, int w, float *M)
+// FarnebackUpdateMatrices at one pixel: the five entries (G11, G12, G22, h1, h2) from the
+// expansions R0 (at the pixel) and R1 (bilinear sample at pixel + flow), with border damping.
+__device__ __forceinline__ void update_matrix_px(const float *R0, const float *R1, const float2 *flow, int x, int y,
+                                                 int h, int w, size_t P, float (&m)[5])
 {
-    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (x >= w || y >= h) return;
-    const size_t p = blockIdx.z;
-    const size_t P = (size_t)h * w;
-    const float *R0 = R + p * 5 * P, *R1 = R0 + 5 * P;
     const size_t o = (size_t)y * w + x;
-    const float2 d = flow[p * P + o];
+    const float2 d = flow[o];
     const float dx = d.x, dy = d.y;
     float fx = x + dx, fy = y + dy;
     const int x1 = (int)floorf(fx), y1 = (int)floorf(fy);
@@ -361,85 +357,135 @@ __global__ __launch_bounds__(256) void update_matrices_kernel(const float *R, co
     r3 += r6 * dy + r5 * dx;
     constexpr int BORDER = 5;
     if ((unsigned)(x - BORDER) >= (unsigned)(w - BORDER * 2) || (unsigned)(y - BORDER) >= (unsigned)(h - BORDER * 2)) {
-        const float border[BORDER] = {0.14f, 0.14f, 0.4472f, 0.4472f, 0.4472f};
-        auto bw = [&](int i) -> float {   // border[i], 0 <= i < 5, without a runtime-indexed array
-            return i < 2 ? 0.14f : 0.4472f;
-        };
-        (void)border;
+        auto bw = [](int i) -> float { return i < 2 ? 0.14f : 0.4472f; };   // {0.14, 0.14, 0.4472, 0.4472, 0.4472}
         const float scale = (x < BORDER ? bw(x) : 1.f) * (x >= w - BORDER ? bw(w - x - 1) : 1.f) *
                             (y < BORDER ? bw(y) : 1.f) * (y >= h - BORDER ? bw(h - y - 1) : 1.f);
         r2 *= scale; r3 *= scale; r4 *= scale; r5 *= scale; r6 *= scale;
     }
-    float *m = M + p * 5 * P + o;
     m[0] = r4 * r4 + r6 * r6;
-    m[P] = (r4 + r5) * r6;
-    m[2 * P] = r5 * r5 + r6 * r6;
-    m[3 * P] = r4 * r2 + r6 * r3;
-    m[4 * P] = r6 * r2 + r5 * r3;
+    m[1] = (r4 + r5) * r6;
+    m[2] = r5 * r5 + r6 * r6;
+    m[3] = r4 * r2 + r6 * r3;
+    m[4] = r6 * r2 + r5 * r3;
 }
 
-// FarnebackUpdateFlow_Blur's box window + solve: M [np][5][h][w] -> flow [np][h][w] (float2).
-// Tile = 64 x 16 outputs; vertical 15-sums (f64, sliding) of 78 columns are staged in LDS, each
-// thread then slides a horizontal 15-window over 4 consecutive outputs.  Replicate borders.
-constexpr int BS_TW = 64, BS_TH = 16, BS_M = 7, BS_COLS = BS_TW + 2 * BS_M;   // winsize 15
-__global__ __launch_bounds__(256) void blur_solve_kernel(const float *M, int h, int w, float2 *flow)
+// One Farneback iteration, fused: FarnebackUpdateMatrices -> 15x15 box window (replicate borders,
+// f64) -> regularised 2x2 solve, flow_in -> flow_out (distinct buffers).  The matrices never
+// touch HBM.  A 512-thread block owns a strip of 114 output columns (128 matrix columns with the
+// window halo) and MARCHES down a segment of rows, 4 rows per step:
+//   A  every thread computes one matrix pixel of the 4 new rows into a 20-row LDS ring;
+//   B  threads own (column, channel) items and keep the running vertical 15-row sum in an f64
+//      register (+ new row - row leaving the window), writing the 4 rows of sums to LDS;
+//   C  horizontal 15-sums slide over two adjacent outputs per thread, then the 2x2 solve.
+// Only the horizontal halo (128/114) and 14 rows per segment are computed twice.
+constexpr int FI_TW = 114, FI_M = 7, FI_MC = 128, FI_G = 4, FI_RING = 20, FI_THREADS = 512;
+constexpr int FI_MROW = 5 * FI_MC;                       // floats per ring row
+__device__ __forceinline__ int fi_vidx(int c) { return (c >> 1) + (c & 1) * (FI_MC / 2); }   // even | odd columns
+
+__global__ __launch_bounds__(FI_THREADS) void flow_iter_kernel(const float *R, const float2 *flow_in, float2 *flow_out,
+                                                               int h, int w, int seg_rows)
 {
-    __shared__ double s_v[5][BS_TH][BS_COLS + 1];
+    __shared__ float s_m[FI_RING * FI_MROW];             // [slot][ch][c]
+    __shared__ double s_v[5 * FI_G * FI_MC];             // [ch][r][vidx(c)]
     const int tid = threadIdx.x;
-    const int x0 = blockIdx.x * BS_TW, y0 = blockIdx.y * BS_TH;
+    const int x0 = blockIdx.x * FI_TW;
+    const int ys = blockIdx.y * seg_rows;
+    if (ys >= h) return;
+    const int ye = min(h, ys + seg_rows);
     const size_t p = blockIdx.z;
     const size_t P = (size_t)h * w;
-    const float *Mp = M + p * 5 * P;
-    for (int item = tid; item < 5 * BS_COLS; item += 256) {
-        const int ch = item / BS_COLS, c = item - ch * BS_COLS;
-        int x = x0 - BS_M + c;
-        x = x < 0 ? 0 : (x > w - 1 ? w - 1 : x);
-        const float *col = Mp + ch * P + x;
-        auto at = [&](int yy) -> double {
-            yy = yy < 0 ? 0 : (yy > h - 1 ? h - 1 : yy);
-            return (double)col[(size_t)yy * w];
-        };
-        double s = 0.0;
+    const float *R0 = R + p * 5 * P, *R1 = R0 + 5 * P;
+    const float2 *fin = flow_in + p * P;
+    float2 *fout = flow_out + p * P;
+
+    const int ac = tid & (FI_MC - 1), ar = tid >> 7;     // phase A: column, row within the group
+    int ax = x0 - FI_M + ac;
+    ax = ax < 0 ? 0 : (ax > w - 1 ? w - 1 : ax);
+    // matrix row j (unclamped) lives in ring slot (j - ys + 8) % 20
+    auto fill_row = [&](int j) {
+        const int y = j < 0 ? 0 : (j > h - 1 ? h - 1 : j);
+        float m[5];
+        update_matrix_px(R0, R1, fin, ax, y, h, w, P, m);
+        float *dst = s_m + ((j - ys + 8) % FI_RING) * FI_MROW + ac;
 #pragma unroll
-        for (int i = -BS_M; i <= BS_M; ++i) s += at(y0 + i);
-        s_v[ch][0][c] = s;
-#pragma unroll 5
-        for (int r = 1; r < BS_TH; ++r) {
-            s += at(y0 + r + BS_M) - at(y0 + r - BS_M - 1);
-            s_v[ch][r][c] = s;
+        for (int ch = 0; ch < 5; ++ch) dst[ch * FI_MC] = m[ch];
+    };
+    // phase B items: (ch = tid >> 7, c = tid & 127) for every thread, (ch = 4, c = tid) for tid < 128
+    const float *col0 = s_m + (tid >> 7) * FI_MC + ac;
+    const float *col1 = s_m + 4 * FI_MC + ac;
+    double *vo0 = s_v + (tid >> 7) * (FI_G * FI_MC) + fi_vidx(ac);
+    double *vo1 = s_v + 4 * (FI_G * FI_MC) + fi_vidx(ac);
+    const bool has1 = tid < FI_MC;
+    double v0 = 0.0, v1 = 0.0;
+
+#pragma unroll 1
+    for (int j = ys - FI_M + ar; j < ys + FI_M; j += FI_G) fill_row(j);    // rows ys-7 .. ys+6
+    int slot_in = 15 % FI_RING;                          // slot of row yb+7 for yb = ys
+    int slot_out = 1;                                    // slot of row ys-7, the first row to leave the window
+#pragma unroll 1
+    for (int yb = ys; yb < ye; yb += FI_G) {
+        fill_row(yb + FI_M + ar);                        // rows yb+7 .. yb+10
+        __syncthreads();
+        if (yb == ys) {                                  // first output row: direct 15-row sum
+            for (int i = 1; i <= 2 * FI_M; ++i) {        // rows ys-7 .. ys+6 = slots 1 .. 14
+                v0 += (double)col0[i * FI_MROW];
+                if (has1) v1 += (double)col1[i * FI_MROW];
+            }
         }
-    }
-    __syncthreads();
-    const int r = tid >> 4, xq = (tid & 15) * 4;
-    const int y = y0 + r;
-    if (y >= h) return;
-    double acc[5][4];
 #pragma unroll
-    for (int ch = 0; ch < 5; ++ch) {
-        const double *v = s_v[ch][r] + xq;
-        double s = 0.0;
-#pragma unroll
-        for (int i = 0; i < 2 * BS_M + 1; ++i) s += v[i];
-        acc[ch][0] = s;
-#pragma unroll
-        for (int j = 1; j < 4; ++j) {
-            s += v[j + 2 * BS_M] - v[j - 1];
-            acc[ch][j] = s;
+        for (int r = 0; r < FI_G; ++r) {
+            if (yb == ys && r == 0) {
+                v0 += (double)col0[slot_in * FI_MROW];
+                if (has1) v1 += (double)col1[slot_in * FI_MROW];
+            } else {
+                v0 += (double)col0[slot_in * FI_MROW] - (double)col0[slot_out * FI_MROW];
+                if (has1) v1 += (double)col1[slot_in * FI_MROW] - (double)col1[slot_out * FI_MROW];
+                slot_out = slot_out + 1 == FI_RING ? 0 : slot_out + 1;
+            }
+            slot_in = slot_in + 1 == FI_RING ? 0 : slot_in + 1;
+            vo0[r * FI_MC] = v0;
+            if (has1) vo1[r * FI_MC] = v1;
         }
-    }
-    const double scale = 1.0 / (double)((2 * BS_M + 1) * (2 * BS_M + 1));
+        __syncthreads();
+        // horizontal sums + solve: waves 0..3, thread -> row r = tid >> 6, outputs 2l, 2l+1 (l < 57)
+        if (tid < 64 * FI_G) {
+            const int r = tid >> 6, l = tid & 63;
+            const int y = yb + r;
+            if (l < FI_TW / 2 && y < ye) {
+                double acc[5][2];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int x = x0 + xq + j;
-        if (x < w) {
-            const double g11 = acc[0][j] * scale, g12 = acc[1][j] * scale, g22 = acc[2][j] * scale,
-                         h1 = acc[3][j] * scale, h2 = acc[4][j] * scale;
-            const double idet = 1. / (g11 * g22 - g12 * g12 + 1e-3);
-            float2 o;
-            o.x = (float)((g11 * h2 - g12 * h1) * idet);
-            o.y = (float)((g22 * h1 - g12 * h2) * idet);
-            flow[p * P + (size_t)y * w + x] = o;
+                for (int ch = 0; ch < 5; ++ch) {
+                    // window of output 2l = matrix columns 2l .. 2l+14; even columns at [l + i], odd at [64 + l + i]
+                    const double *ve = s_v + ch * (FI_G * FI_MC) + r * FI_MC + l;
+                    const double *vd = ve + FI_MC / 2;
+                    double s = ve[0];
+#pragma unroll
+                    for (int i = 1; i <= FI_M; ++i) s += vd[i - 1] + ve[i];
+                    acc[ch][0] = s;
+                    acc[ch][1] = s + (vd[FI_M] - ve[0]);
+                }
+                const double scale = 1.0 / (double)((2 * FI_M + 1) * (2 * FI_M + 1));
+                float2 o[2];
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const double g11 = acc[0][j] * scale, g12 = acc[1][j] * scale, g22 = acc[2][j] * scale,
+                                 h1 = acc[3][j] * scale, h2 = acc[4][j] * scale;
+                    const double idet = 1. / (g11 * g22 - g12 * g12 + 1e-3);
+                    o[j].x = (float)((g11 * h2 - g12 * h1) * idet);
+                    o[j].y = (float)((g22 * h1 - g12 * h2) * idet);
+                }
+                const int x = x0 + 2 * l;
+                float2 *dst = fout + (size_t)y * w + x;
+                if (x + 1 < w && ((w & 1) == 0)) {
+                    *reinterpret_cast<float4 *>(dst) = make_float4(o[0].x, o[0].y, o[1].x, o[1].y);
+                } else {
+                    if (x < w) dst[0] = o[0];
+                    if (x + 1 < w) dst[1] = o[1];
+                }
+            }
         }
+        // the next step's fill_row only writes ring rows that this step no longer reads, and the
+        // barrier after it orders this step's s_v reads before the next step's s_v writes
     }
 }
 
@@ -583,47 +629,53 @@ int run_pairs(ipx_ctx *ctx, const uint8_t *frames, const uint8_t *extra, int fir
     const ipx_flow_plan *pl = ctx->flow_plan;
     const int nf = np + 1;
     const size_t P0 = (size_t)pl->lv[0].lh * pl->lv[0].lw;
-    void *pyr, *mat, *uv;
-    IPX_TRY(ipx_scratch(ctx, SLOT_FLOW_PYR, (size_t)nf * P0 * 6 * sizeof(float), &pyr));
-    IPX_TRY(ipx_scratch(ctx, SLOT_FLOW_MAT, (size_t)np * P0 * 5 * sizeof(float), &mat));
-    const size_t P1 = pl->levels > 0 ? (size_t)pl->lv[1].lh * pl->lv[1].lw : 0;
-    IPX_TRY(ipx_scratch(ctx, SLOT_FLOW_UV, (size_t)np * (P0 + P1) * sizeof(float2) + 256, &uv));
-    float2 *uvA = (float2 *)uv;                                   // holds levels 0, 2, ...
-    float2 *uvB = uvA + ipx_align_up((size_t)np * P0, 32);       // holds levels 1, 3, ...
-    float2 *prev = nullptr;
+    void *pyr, *uv;
+    IPX_TRY(ipx_scratch(ctx, SLOT_FLOW_PYR, (size_t)nf * P0 * 6 * sizeof(float) + 512, &pyr));
+    IPX_TRY(ipx_scratch(ctx, SLOT_FLOW_UV, 2 * (size_t)np * P0 * sizeof(float2) + 512, &uv));
+    // two flow buffers: X receives the initial flow of a level (zeros / upsampled), the three
+    // iterations go X -> Y -> X -> Y, so a level's result is always in Y and the next level's
+    // upsampling reads Y and writes X
+    float2 *X = (float2 *)uv, *Y = X + ipx_align_up((size_t)np * P0, 32);
+    bool have_prev = false;
     const dim3 block(256);
     for (int k = pl->levels; k >= 0; --k) {
         const LevelGeom &g = pl->lv[k];
         const size_t P = (size_t)g.lh * g.lw;
         float *I = (float *)pyr, *R = I + ipx_align_up((size_t)nf * P, 64);
-        float *M = (float *)mat;
-        float2 *cur = (k & 1) ? uvB : uvA;
         IPX_TRY(launch_level_expansion(ctx, g, frames, extra, first, nf, I, R));
-        if (!prev) {
-            IPX_CHECK_HIP(hipMemsetAsync(cur, 0, (size_t)np * P * sizeof(float2), ctx->stream));
+        if (!have_prev) {
+            IPX_CHECK_HIP(hipMemsetAsync(X, 0, (size_t)np * P * sizeof(float2), ctx->stream));
         } else {
             const LevelGeom &c = pl->lv[k + 1];
-            IPX_LAUNCH(ctx, KID_UPSAMPLE, 8.0 * np * ((double)g.lh * g.lw + (double)c.lh * c.lw), flow_upsample_kernel, grid64x4(g.lw, g.lh, np), block, prev, c.lh, c.lw,
-                               cur, g.lh, g.lw, g.ux_ofs, g.ux_a, g.uy_ofs, g.uy_b);
+            IPX_LAUNCH(ctx, KID_UPSAMPLE, 8.0 * np * ((double)g.lh * g.lw + (double)c.lh * c.lw), flow_upsample_kernel,
+                       grid64x4(g.lw, g.lh, np), block, Y, c.lh, c.lw, X, g.lh, g.lw, g.ux_ofs, g.ux_a, g.uy_ofs, g.uy_b);
         }
-        IPX_LAUNCH(ctx, KID_UPDATE_MATRICES, 68.0 * np * P, update_matrices_kernel, grid64x4(g.lw, g.lh, np), block, R, cur, g.lh, g.lw, M);
-        const dim3 bgrid((g.lw + BS_TW - 1) / BS_TW, (g.lh + BS_TH - 1) / BS_TH, np);
+        // segments of rows per strip so that a launch has a few thousand blocks
+        const int strips = (g.lw + FI_TW - 1) / FI_TW;
+        int nseg = (4096 + strips * np - 1) / (strips * np);
+        const int max_seg = (g.lh + 63) / 64;
+        if (nseg > max_seg) nseg = max_seg;
+        if (nseg < 1) nseg = 1;
+        int seg_rows = (g.lh + nseg - 1) / nseg;
+        seg_rows = (seg_rows + FI_G - 1) / FI_G * FI_G;
+        nseg = (g.lh + seg_rows - 1) / seg_rows;
+        const dim3 fgrid(strips, nseg, np), fblock(FI_THREADS);
         for (int it = 0; it < 3; ++it) {                            // ip.py:864 iterations=3
-            IPX_LAUNCH(ctx, KID_BLUR_SOLVE, 28.0 * np * P, blur_solve_kernel, bgrid, block, M, g.lh, g.lw, cur);
-            if (it < 2)
-                IPX_LAUNCH(ctx, KID_UPDATE_MATRICES, 68.0 * np * P, update_matrices_kernel, grid64x4(g.lw, g.lh, np), block, R, cur, g.lh, g.lw, M);
+            const float2 *src = (it & 1) ? Y : X;
+            float2 *dst = (it & 1) ? X : Y;
+            IPX_LAUNCH(ctx, KID_FLOW_ITER, 56.0 * np * P, flow_iter_kernel, fgrid, fblock, R, src, dst, g.lh, g.lw, seg_rows);
         }
         IPX_LAUNCH_CHECK();
-        prev = cur;
+        have_prev = true;
     }
-    *uv_out = prev;
+    *uv_out = Y;
     return IPX_OK;
 }
 
 // pairs per batch: bounded by a scratch budget and by grid.z
 int pair_batch(int H, int W, int want)
 {
-    const size_t per_pair = (size_t)H * W * (6 + 5 + 3) * sizeof(float);
+    const size_t per_pair = (size_t)H * W * (6 + 4) * sizeof(float);
     size_t b = ((size_t)6 << 30) / per_pair;
     if (b < 1) b = 1;
     if (b > 64) b = 64;

@@ -14,7 +14,6 @@ enum ipx_slot {
     SLOT_STAGE,          // single-stage entry points (ipx_background's dummy plane, ...)
     SLOT_FLOW_TAB,       // flow.hip: per-(H,W) resize / filter tables
     SLOT_FLOW_PYR,       // flow.hip: level images + polynomial expansions of a batch
-    SLOT_FLOW_MAT,       // flow.hip: G/h matrices of a batch
     SLOT_FLOW_UV,        // flow.hip: flow fields (two levels, ping-pong)
     SLOT_FLOW_RED,       // flow.hip: partial sums of the magnitude reduction
     WS_RAW, WS_BRIGHT, WS_PERS, WS_STATIC, WS_FINAL, WS_MAPS, WS_COUNTS,   // chunk.hip
@@ -27,7 +26,7 @@ struct ipx_flow_plan;   // flow.hip
 // stream around every launch, accumulated per class together with the launch's ALGORITHMIC bytes
 // (compulsory reads + writes: every input and output array counted once; DESIGN.md lists them).
 enum ipx_kid {
-    KID_PYR = 0, KID_POLYEXP, KID_UPSAMPLE, KID_UPDATE_MATRICES, KID_BLUR_SOLVE, KID_MAGNITUDE,
+    KID_PYR = 0, KID_POLYEXP, KID_UPSAMPLE, KID_FLOW_ITER, KID_MAGNITUDE,
     KID_DETECT, KID_DAMAGED_MASK,
     KID_CCL_INIT, KID_CCL_MERGE, KID_CCL_REDUCE, KID_CCL_SELECT, KID_CLOSE, KID_CLUSTER_EVAL,
     KID_PERSISTENT, KID_STATIC_MAPS, KID_STATIC_FROM_MAPS, KID_FINALIZE, KID_MISC,
