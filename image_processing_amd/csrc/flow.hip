@@ -42,6 +42,12 @@ struct LevelGeom {
     const float *x_a;    // [lw]  weight of the second tap
     const int *y_ofs;    // [lh][2] clamped source rows
     const float *y_b;    // [lh]  weight of the second row
+    // tiled pyramid kernel: the two source columns / rows every level pixel samples (equal in mode 0)
+    const int *xs2;      // [lw][2]
+    const int *ys2;      // [lh][2]
+    int tox, toy;        // level pixels per tile
+    int src_rows, src_cols, src_pitch, tmp_pitch;   // staged source window (max over tiles) and LDS pitches
+    unsigned lds_bytes;
     // upsampling of the previous (coarser) level's flow to this level
     const int *ux_ofs; const float *ux_a; const int *uy_ofs; const float *uy_b;
 };
@@ -202,46 +208,126 @@ struct PyrArgs {
     const uint8_t *extra;      // optional frame standing in for index -1 (left halo), may be null
     int first;                 // chunk index of launch frame 0 (may be -1 when `extra` is given)
     int H, W, lh, lw, mode;
-    const int *x_ofs; const float *x_a; const int *y_ofs; const float *y_b;
+    int tox, toy, src_pitch, tmp_pitch, src_rows;
+    const int *xs2; const float *x_a; const int *ys2; const float *y_b;
     float *out;                // [nf][lh][lw]
     KernTaps kt;
 };
 
-// One thread per level pixel: blur at the 1, 4 (area) or 4 (linear) source positions it needs.
+// Pyramid level image of one frame: GaussianBlur(frame as f32, KS x KS) sampled at the source
+// positions the linear resize needs, then the resize itself.  One block = tox x toy level pixels:
+//   1. the source window (reflect-101 applied) is staged in LDS as f32,
+//   2. the row pass is evaluated for every staged row at the sampled columns only (lanes = rows,
+//      odd pitches: conflict-free), tap order as blurred_at/row_pass above,
+//   3. each level pixel runs the column pass at its (row, column) samples and combines them
+//      (copy / 2x2 mean / two-tap linear, cv::resize INTER_LINEAR semantics).
 template <int KS>
 __global__ __launch_bounds__(256) void pyr_level_kernel(PyrArgs a)
 {
-    const int dx = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int dy = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (dx >= a.lw || dy >= a.lh) return;
-    const int f = blockIdx.z;
-    const int fi = a.first + f;
+    extern __shared__ __align__(16) unsigned char pyr_smem[];
+    constexpr int R = KS / 2;
+    float *s_src = reinterpret_cast<float *>(pyr_smem);
+    float *s_tmp = s_src + a.src_rows * a.src_pitch;
+    int *s_col = reinterpret_cast<int *>(s_tmp + a.src_rows * a.tmp_pitch);
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int ns = a.mode == 0 ? 1 : 2;
+    const int dx0 = blockIdx.x * a.tox, dy0 = blockIdx.y * a.toy;
+    const int ndx = min(a.tox, a.lw - dx0), ndy = min(a.toy, a.lh - dy0);
+    const int f = blockIdx.z, fi = a.first + f;
     const uint8_t *frame = fi < 0 ? a.extra : a.frames + (size_t)fi * a.H * a.W;
-    float v;
-    if (a.mode == 0) {
-        v = blurred_at<KS>(frame, dy, dx, a.H, a.W, a.kt);
-    } else if (a.mode == 1) {
-        const float s00 = blurred_at<KS>(frame, 2 * dy, 2 * dx, a.H, a.W, a.kt);
-        const float s01 = blurred_at<KS>(frame, 2 * dy, 2 * dx + 1, a.H, a.W, a.kt);
-        const float s10 = blurred_at<KS>(frame, 2 * dy + 1, 2 * dx, a.H, a.W, a.kt);
-        const float s11 = blurred_at<KS>(frame, 2 * dy + 1, 2 * dx + 1, a.H, a.W, a.kt);
-        v = (s00 + s01 + s10 + s11) * 0.25f;
-    } else {
-        const int sx = a.x_ofs[dx];
-        const float a1 = a.x_a[dx], a0 = 1.f - a1;
-        const int y0 = a.y_ofs[2 * dy], y1 = a.y_ofs[2 * dy + 1];
-        const float b1 = a.y_b[dy], b0 = 1.f - b1;
-        float h0, h1;
-        if (sx >= a.W - 1) {
-            h0 = blurred_at<KS>(frame, y0, sx, a.H, a.W, a.kt);
-            h1 = blurred_at<KS>(frame, y1, sx, a.H, a.W, a.kt);
-        } else {
-            h0 = blurred_at<KS>(frame, y0, sx, a.H, a.W, a.kt) * a0 + blurred_at<KS>(frame, y0, sx + 1, a.H, a.W, a.kt) * a1;
-            h1 = blurred_at<KS>(frame, y1, sx, a.H, a.W, a.kt) * a0 + blurred_at<KS>(frame, y1, sx + 1, a.H, a.W, a.kt) * a1;
+    const int xlo = a.xs2[2 * dx0], xhi = a.xs2[2 * (dx0 + ndx - 1) + 1];
+    const int ylo = a.ys2[2 * dy0], yhi = a.ys2[2 * (dy0 + ndy - 1) + 1];
+    const int c_lo = xlo - R, c_hi = xhi + R;              // staged columns c_org .. c_hi, c_org = c_lo rounded down to 4
+    const int c_org = c_lo & ~3, ndw = (c_hi - c_org + 4) >> 2;
+    const int r_lo = ylo - R, nrows = yhi - ylo + 1 + 2 * R;
+    const int nsamp = ns * ndx;
+    // 1. stage the source window as f32 (LDS column = source column - c_org)
+    if (c_org >= 0 && c_org + 4 * ndw <= a.W && r_lo >= 0 && r_lo + nrows <= a.H && (a.W & 3) == 0) {
+        // interior tile: aligned dword loads, four independent loads in flight per thread
+        const int total = nrows * ndw;
+        const int dq = 256 % ndw, dr = 256 / ndw;
+        int r = tid / ndw, q = tid - r * ndw;
+        const uint8_t *base = frame + (size_t)r_lo * a.W + c_org;
+        for (int i0 = tid; i0 < total; i0 += 4 * 256) {
+            uint32_t v[4]; int rr[4], qq[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                rr[u] = r; qq[u] = q;
+                v[u] = (i0 + u * 256 < total) ? *reinterpret_cast<const uint32_t *>(base + (size_t)r * a.W + 4 * q) : 0u;
+                q += dq; r += dr;
+                if (q >= ndw) { q -= ndw; ++r; }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (i0 + u * 256 < total) {
+                    float *d = s_src + rr[u] * a.src_pitch + 4 * qq[u];
+                    d[0] = (float)(v[u] & 0xff); d[1] = (float)((v[u] >> 8) & 0xff);
+                    d[2] = (float)((v[u] >> 16) & 0xff); d[3] = (float)(v[u] >> 24);
+                }
         }
-        v = h0 * b0 + h1 * b1;
+    } else {
+        const int ncols = c_hi - c_org + 1;
+        for (int r = wv; r < nrows; r += 4) {
+            const uint8_t *row = frame + (size_t)reflect101(r_lo + r, a.H) * a.W;
+            for (int c = lane; c < ncols; c += 64) s_src[r * a.src_pitch + c] = (float)row[reflect101(c_org + c, a.W)];
+        }
     }
-    a.out[((size_t)f * a.lh + dy) * a.lw + dx] = v;
+    for (int s = tid; s < nsamp; s += 256)
+        s_col[s] = (ns == 1 ? a.xs2[2 * (dx0 + s)] : a.xs2[2 * (dx0 + (s >> 1)) + (s & 1)]) - c_org;
+    __syncthreads();
+    // 2. row pass: wave -> sample, lane -> staged row
+    for (int s = wv; s < nsamp; s += 4) {
+        const int cc = s_col[s];
+        for (int r = lane; r < nrows; r += 64) {
+            const float *S = s_src + r * a.src_pitch + cc;
+            float v;
+            if (KS <= 5) {
+                v = S[0] * a.kt.k[R];
+#pragma unroll
+                for (int j = 1; j <= R; ++j) v += (S[-j] + S[j]) * a.kt.k[R + j];
+            } else {
+                v = S[-R] * a.kt.k[0];
+#pragma unroll
+                for (int i = 1; i < KS; ++i) v += S[i - R] * a.kt.k[i];
+            }
+            s_tmp[r * a.tmp_pitch + s] = v;
+        }
+    }
+    __syncthreads();
+    // 3. column pass + resize
+    auto col_pass = [&](int r, int s) -> float {
+        const float *T = s_tmp + r * a.tmp_pitch + s;
+        float v = a.kt.k[R] * T[0];
+#pragma unroll
+        for (int j = 1; j <= R; ++j) v += a.kt.k[R + j] * (T[j * a.tmp_pitch] + T[-j * a.tmp_pitch]);
+        return v;
+    };
+    for (int idx = tid; idx < a.tox * ndy; idx += 256) {
+        const int dyl = idx / a.tox, dxl = idx - dyl * a.tox;
+        if (dxl >= ndx) continue;
+        const int dx = dx0 + dxl, dy = dy0 + dyl;
+        const int ra = a.ys2[2 * dy] - r_lo, rb = a.ys2[2 * dy + 1] - r_lo;
+        float v;
+        if (a.mode == 0) {
+            v = col_pass(ra, dxl);
+        } else if (a.mode == 1) {
+            const float s00 = col_pass(ra, 2 * dxl), s01 = col_pass(ra, 2 * dxl + 1);
+            const float s10 = col_pass(rb, 2 * dxl), s11 = col_pass(rb, 2 * dxl + 1);
+            v = (s00 + s01 + s10 + s11) * 0.25f;
+        } else {
+            const float a1 = a.x_a[dx], a0 = 1.f - a1, b1 = a.y_b[dy], b0 = 1.f - b1;
+            float h0, h1;
+            if (a.xs2[2 * dx] >= a.W - 1) {                   // right edge: single tap
+                h0 = col_pass(ra, 2 * dxl);
+                h1 = col_pass(rb, 2 * dxl);
+            } else {
+                h0 = col_pass(ra, 2 * dxl) * a0 + col_pass(ra, 2 * dxl + 1) * a1;
+                h1 = col_pass(rb, 2 * dxl) * a0 + col_pass(rb, 2 * dxl + 1) * a1;
+            }
+            v = h0 * b0 + h1 * b1;
+        }
+        a.out[((size_t)f * a.lh + dy) * a.lw + dx] = v;
+    }
 }
 
 // FarnebackPolyExp: I [nf][h][w] -> R [nf][5][h][w].  Block = 64 columns x 4 rows; the vertical
@@ -552,7 +638,7 @@ int build_plan(ipx_ctx *ctx, int H, int W)
         memcpy(host.data() + off, src, bytes);
         return off;
     };
-    size_t offs[MAX_LEVELS][8];
+    size_t offs[MAX_LEVELS][10];
     for (int k = 0; k <= levels; ++k) {
         LevelGeom &g = pl->lv[k];
         double scale = 1;
@@ -570,6 +656,48 @@ int build_plan(ipx_ctx *ctx, int H, int W)
         linear_table_y(H, g.lh, yo, yb);
         offs[k][0] = push(xo.data(), xo.size() * 4); offs[k][1] = push(xa.data(), xa.size() * 4);
         offs[k][2] = push(yo.data(), yo.size() * 4); offs[k][3] = push(yb.data(), yb.size() * 4);
+        // sample columns / rows of every level pixel, all three resize modes in one form
+        std::vector<int> xs2(2 * (size_t)g.lw), ys2(2 * (size_t)g.lh);
+        for (int d = 0; d < g.lw; ++d) {
+            if (g.mode == 0) xs2[2 * d] = xs2[2 * d + 1] = d;
+            else if (g.mode == 1) { xs2[2 * d] = 2 * d; xs2[2 * d + 1] = 2 * d + 1; }
+            else { xs2[2 * d] = xo[d]; xs2[2 * d + 1] = xo[d] + 1 > W - 1 ? W - 1 : xo[d] + 1; }
+        }
+        for (int d = 0; d < g.lh; ++d) {
+            if (g.mode == 0) ys2[2 * d] = ys2[2 * d + 1] = d;
+            else if (g.mode == 1) { ys2[2 * d] = 2 * d; ys2[2 * d + 1] = 2 * d + 1; }
+            else { ys2[2 * d] = yo[2 * d]; ys2[2 * d + 1] = yo[2 * d + 1]; }
+        }
+        offs[k][8] = push(xs2.data(), xs2.size() * 4); offs[k][9] = push(ys2.data(), ys2.size() * 4);
+        // tile: as many level rows as keep the staged source window within 64 rows (one lane per row in
+        // the row pass), as many level columns as keep the staged window within ~36 KB of LDS
+        const int Rk = g.ksize / 2;
+        auto extent = [&](const std::vector<int> &t2, int n, int tile) {
+            int mx = 0;
+            for (int d0 = 0; d0 < n; d0 += tile) {
+                const int d1 = d0 + tile - 1 < n - 1 ? d0 + tile - 1 : n - 1;
+                const int e = t2[2 * d1 + 1] - t2[2 * d0] + 1 + 2 * Rk;
+                if (e > mx) mx = e;
+            }
+            return mx;
+        };
+        int toy = 1;
+        while (toy < g.lh && toy < 64 && extent(ys2, g.lh, toy + 1) <= 64) ++toy;
+        g.toy = toy;
+        g.src_rows = extent(ys2, g.lh, toy);
+        const int nsx = g.mode == 0 ? 1 : 2;
+        auto lds_for = [&](int tx) {
+            const int sp = (extent(xs2, g.lw, tx) + 7) | 1, tp = (nsx * tx) | 1;
+            return ((size_t)g.src_rows * (sp + tp) + 2 * tx) * 4 + 16;
+        };
+        int tox = 64;
+        while (tox > 8 && lds_for(tox) > 52 * 1024) tox >>= 1;
+        g.tox = tox;
+        g.src_cols = extent(xs2, g.lw, tox);
+        g.src_pitch = (g.src_cols + 7) | 1;
+        g.tmp_pitch = (nsx * tox) | 1;
+        g.lds_bytes = (unsigned)lds_for(tox);
+        if (g.lds_bytes > 64 * 1024) { delete pl; ipx_set_error("pyramid tile does not fit in LDS (%u bytes)", g.lds_bytes); return IPX_ERR_UNSUPPORTED; }
     }
     for (int k = 0; k < levels; ++k) {                       // flow of level k from level k+1
         std::vector<int> xo, yo; std::vector<float> xa, yb;
@@ -589,6 +717,7 @@ int build_plan(ipx_ctx *ctx, int H, int W)
         LevelGeom &g = pl->lv[k];
         g.x_ofs = (const int *)(d + offs[k][0]); g.x_a = (const float *)(d + offs[k][1]);
         g.y_ofs = (const int *)(d + offs[k][2]); g.y_b = (const float *)(d + offs[k][3]);
+        g.xs2 = (const int *)(d + offs[k][8]); g.ys2 = (const int *)(d + offs[k][9]);
         if (k < levels) {
             g.ux_ofs = (const int *)(d + offs[k][4]); g.ux_a = (const float *)(d + offs[k][5]);
             g.uy_ofs = (const int *)(d + offs[k][6]); g.uy_b = (const float *)(d + offs[k][7]);
@@ -607,17 +736,21 @@ int launch_level_expansion(ipx_ctx *ctx, const LevelGeom &g, const uint8_t *fram
     const ipx_flow_plan *pl = ctx->flow_plan;
     PyrArgs a;
     a.frames = frames; a.extra = extra; a.first = first; a.H = pl->H; a.W = pl->W; a.lh = g.lh; a.lw = g.lw;
-    a.mode = g.mode; a.x_ofs = g.x_ofs; a.x_a = g.x_a; a.y_ofs = g.y_ofs; a.y_b = g.y_b; a.out = I;
+    a.mode = g.mode; a.tox = g.tox; a.toy = g.toy; a.src_pitch = g.src_pitch; a.tmp_pitch = g.tmp_pitch;
+    a.src_rows = g.src_rows; a.xs2 = g.xs2; a.x_a = g.x_a; a.ys2 = g.ys2; a.y_b = g.y_b; a.out = I;
     memcpy(a.kt.k, g.kern, sizeof(a.kt.k));
-    const dim3 grid = grid64x4(g.lw, g.lh, nf), block(256);
+    const dim3 grid((g.lw + g.tox - 1) / g.tox, (g.lh + g.toy - 1) / g.toy, nf), block(256);
+    const double pyr_bytes = (double)nf * ((double)pl->H * pl->W + 4.0 * g.lh * g.lw);
+    if (ctx->prof.on) ipx_prof_begin(ctx, KID_PYR, pyr_bytes);
     switch (g.ksize) {
-    case 3: IPX_LAUNCH(ctx, KID_PYR, (double)nf * ((double)pl->H * pl->W + 4.0 * g.lh * g.lw), pyr_level_kernel<3>, grid, block, a); break;
-    case 9: IPX_LAUNCH(ctx, KID_PYR, (double)nf * ((double)pl->H * pl->W + 4.0 * g.lh * g.lw), pyr_level_kernel<9>, grid, block, a); break;
-    case 19: IPX_LAUNCH(ctx, KID_PYR, (double)nf * ((double)pl->H * pl->W + 4.0 * g.lh * g.lw), pyr_level_kernel<19>, grid, block, a); break;
+    case 3: hipLaunchKernelGGL(pyr_level_kernel<3>, grid, block, g.lds_bytes, ctx->stream, a); break;
+    case 9: hipLaunchKernelGGL(pyr_level_kernel<9>, grid, block, g.lds_bytes, ctx->stream, a); break;
+    case 19: hipLaunchKernelGGL(pyr_level_kernel<19>, grid, block, g.lds_bytes, ctx->stream, a); break;
     default:
         ipx_set_error("Gaussian aperture %d unsupported", g.ksize);
         return IPX_ERR_UNSUPPORTED;
     }
+    if (ctx->prof.on) ipx_prof_end(ctx);
     IPX_LAUNCH(ctx, KID_POLYEXP, 24.0 * nf * g.lh * g.lw, polyexp_kernel, dim3((g.lw + PX_TW - 1) / PX_TW, (g.lh + PX_TH - 1) / PX_TH, nf), block, I, g.lh, g.lw, pl->pc, R);
     IPX_LAUNCH_CHECK();
     return IPX_OK;
