@@ -24,6 +24,7 @@
 #include <math.h>
 #include <float.h>
 #include <string.h>
+#include <stdlib.h>
 #include <vector>
 
 namespace {
@@ -167,42 +168,9 @@ __device__ __forceinline__ int reflect101(int p, int len)
 
 struct KernTaps { float k[MAX_KS]; };
 
-// GaussianBlur(frame as f32, (KS,KS), sigma) at one full-resolution position, BORDER_REFLECT_101:
-// row pass then column pass in f32, tap order as the separable filter engine evaluates it
-// (symmetric pairing for apertures <= 5 in the row pass, left-to-right otherwise; symmetric
-// pairing from the centre outwards in the column pass).
-template <int KS>
-__device__ __forceinline__ float row_pass(const uint8_t *row, int x, int W, const KernTaps &kt)
-{
-    constexpr int R = KS / 2;
-    float s;
-    if (KS <= 5) {
-        s = (float)row[x] * kt.k[R];
-#pragma unroll
-        for (int j = 1; j <= R; ++j)
-            s += ((float)row[reflect101(x - j, W)] + (float)row[reflect101(x + j, W)]) * kt.k[R + j];
-    } else {
-        s = (float)row[reflect101(x - R, W)] * kt.k[0];
-#pragma unroll
-        for (int i = 1; i < KS; ++i) s += (float)row[reflect101(x - R + i, W)] * kt.k[i];
-    }
-    return s;
-}
-
-template <int KS>
-__device__ __forceinline__ float blurred_at(const uint8_t *frame, int y, int x, int H, int W, const KernTaps &kt)
-{
-    constexpr int R = KS / 2;
-    float s = kt.k[R] * row_pass<KS>(frame + (size_t)y * W, x, W, kt);
-#pragma unroll 1
-    for (int j = 1; j <= R; ++j) {
-        const float lo = row_pass<KS>(frame + (size_t)reflect101(y + j, H) * W, x, W, kt);
-        const float hi = row_pass<KS>(frame + (size_t)reflect101(y - j, H) * W, x, W, kt);
-        s += kt.k[R + j] * (lo + hi);
-    }
-    return s;
-}
-
+// Tap order of GaussianBlur(frame as f32, (KS,KS), sigma), BORDER_REFLECT_101, as the separable filter
+// engine evaluates it: row pass then column pass in f32; symmetric pairing for apertures <= 5 in the
+// row pass, left-to-right otherwise; symmetric pairing from the centre outwards in the column pass.
 struct PyrArgs {
     const uint8_t *frames;     // frame f of this launch = frames + frame_index(f) * H * W
     const uint8_t *extra;      // optional frame standing in for index -1 (left halo), may be null
@@ -410,35 +378,73 @@ __global__ void flow_upsample_kernel(const float2 *src, int sh, int sw, float2 *
 
 // FarnebackUpdateMatrices at one pixel: the five entries (G11, G12, G22, h1, h2) from the
 // expansions R0 (at the pixel) and R1 (bilinear sample at pixel + flow), with border damping.
-__device__ __forceinline__ void update_matrix_px(const float *R0, const float *R1, const float2 *flow, int x, int y,
-                                                 int h, int w, size_t P, float (&m)[5])
+// Split into the loads and the arithmetic so that a caller can keep the loads in flight.
+struct UmIn {
+    float r0[5];        // R0 at the pixel
+    float q[5][4];      // R1 at (x1,y1), (x1+1,y1), (x1,y1+1), (x1+1,y1+1); unset when the sample is out of bounds
+};
+
+// bilinear sample position of pixel (x,y) displaced by d: integer corner, fractions, in-bounds test
+__device__ __forceinline__ bool um_position(float2 d, int x, int y, int h, int w, int &x1, int &y1, float &fx, float &fy)
 {
-    const size_t o = (size_t)y * w + x;
-    const float2 d = flow[o];
-    const float dx = d.x, dy = d.y;
-    float fx = x + dx, fy = y + dy;
-    const int x1 = (int)floorf(fx), y1 = (int)floorf(fy);
-    float r2, r3, r4, r5, r6;
+    fx = x + d.x; fy = y + d.y;
+    x1 = (int)floorf(fx); y1 = (int)floorf(fy);
     fx -= x1; fy -= y1;
-    if ((unsigned)x1 < (unsigned)(w - 1) && (unsigned)y1 < (unsigned)(h - 1)) {
-        const float *q = R1 + (size_t)y1 * w + x1;
+    return (unsigned)x1 < (unsigned)(w - 1) && (unsigned)y1 < (unsigned)(h - 1);
+}
+
+// Buffer addressing (SGPR resource + SGPR plane offset + one 32-bit VGPR offset per position) keeps the
+// address arithmetic of the 16 loads of a matrix pixel out of the vector ALU and out of the VGPR file.
+typedef unsigned int ipx_u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t ipx_make_rsrc(const void *base, unsigned bytes)
+{
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, (int)bytes, 0x00020000);
+}
+
+// rR: the pair's expansions, R0 planes 0..4 then R1 planes 5..9, P4 = bytes per plane
+__device__ __forceinline__ void um_load(__amdgpu_buffer_rsrc_t rR, unsigned P4, float2 d, int x, int y, int h, int w, UmIn &in)
+{
+    const unsigned o4 = (unsigned)(y * w + x) * 4u;
+    int x1, y1; float fx, fy;
+    const bool inb = um_position(d, x, y, h, w, x1, y1, fx, fy);
+#pragma unroll
+    for (int c = 0; c < 5; ++c) in.r0[c] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rR, o4, c * P4, 0));
+    if (inb) {
+        const unsigned q0 = (unsigned)(y1 * w + x1) * 4u, q1 = q0 + (unsigned)w * 4u;
+#pragma unroll
+        for (int c = 0; c < 5; ++c) {
+            const ipx_u32x2 a = __builtin_amdgcn_raw_buffer_load_b64(rR, q0, (5 + c) * P4, 0);
+            const ipx_u32x2 b = __builtin_amdgcn_raw_buffer_load_b64(rR, q1, (5 + c) * P4, 0);
+            in.q[c][0] = __uint_as_float(a.x); in.q[c][1] = __uint_as_float(a.y);
+            in.q[c][2] = __uint_as_float(b.x); in.q[c][3] = __uint_as_float(b.y);
+        }
+    }
+}
+
+__device__ __forceinline__ void um_finish(const UmIn &in, float2 d, int x, int y, int h, int w, float (&m)[5])
+{
+    const float dx = d.x, dy = d.y;
+    int x1, y1; float fx, fy;
+    const bool inb = um_position(d, x, y, h, w, x1, y1, fx, fy);
+    float r2, r3, r4, r5, r6;
+    if (inb) {
         const float a00 = (1.f - fx) * (1.f - fy), a01 = fx * (1.f - fy), a10 = (1.f - fx) * fy, a11 = fx * fy;
-        r2 = a00 * q[0] + a01 * q[1] + a10 * q[w] + a11 * q[w + 1];
-        q += P; r3 = a00 * q[0] + a01 * q[1] + a10 * q[w] + a11 * q[w + 1];
-        q += P; r4 = a00 * q[0] + a01 * q[1] + a10 * q[w] + a11 * q[w + 1];
-        q += P; r5 = a00 * q[0] + a01 * q[1] + a10 * q[w] + a11 * q[w + 1];
-        q += P; r6 = a00 * q[0] + a01 * q[1] + a10 * q[w] + a11 * q[w + 1];
-        r4 = (R0[2 * P + o] + r4) * 0.5f;
-        r5 = (R0[3 * P + o] + r5) * 0.5f;
-        r6 = (R0[4 * P + o] + r6) * 0.25f;
+        r2 = a00 * in.q[0][0] + a01 * in.q[0][1] + a10 * in.q[0][2] + a11 * in.q[0][3];
+        r3 = a00 * in.q[1][0] + a01 * in.q[1][1] + a10 * in.q[1][2] + a11 * in.q[1][3];
+        r4 = a00 * in.q[2][0] + a01 * in.q[2][1] + a10 * in.q[2][2] + a11 * in.q[2][3];
+        r5 = a00 * in.q[3][0] + a01 * in.q[3][1] + a10 * in.q[3][2] + a11 * in.q[3][3];
+        r6 = a00 * in.q[4][0] + a01 * in.q[4][1] + a10 * in.q[4][2] + a11 * in.q[4][3];
+        r4 = (in.r0[2] + r4) * 0.5f;
+        r5 = (in.r0[3] + r5) * 0.5f;
+        r6 = (in.r0[4] + r6) * 0.25f;
     } else {
         r2 = r3 = 0.f;
-        r4 = R0[2 * P + o];
-        r5 = R0[3 * P + o];
-        r6 = R0[4 * P + o] * 0.5f;
+        r4 = in.r0[2];
+        r5 = in.r0[3];
+        r6 = in.r0[4] * 0.5f;
     }
-    r2 = (R0[o] - r2) * 0.5f;
-    r3 = (R0[P + o] - r3) * 0.5f;
+    r2 = (in.r0[0] - r2) * 0.5f;
+    r3 = (in.r0[1] - r3) * 0.5f;
     r2 += r4 * dy + r6 * dx;
     r3 += r6 * dy + r5 * dx;
     constexpr int BORDER = 5;
@@ -459,20 +465,24 @@ __device__ __forceinline__ void update_matrix_px(const float *R0, const float *R
 // f64) -> regularised 2x2 solve, flow_in -> flow_out (distinct buffers).  The matrices never
 // touch HBM.  A 512-thread block owns a strip of 114 output columns (128 matrix columns with the
 // window halo) and MARCHES down a segment of rows, 4 rows per step:
-//   A  every thread computes one matrix pixel of the 4 new rows into a 20-row LDS ring;
+//   A  every thread computes one matrix pixel of the 4 new rows into a 20-row LDS ring (the flow
+//      vector of the next step's pixel is already in flight);
 //   B  threads own (column, channel) items and keep the running vertical 15-row sum in an f64
 //      register (+ new row - row leaving the window), writing the 4 rows of sums to LDS;
-//   C  horizontal 15-sums slide over two adjacent outputs per thread, then the 2x2 solve.
+//   C  horizontal 15-sums slide over two adjacent outputs per thread (waves 0-3), then the 2x2 solve.
 // Only the horizontal halo (128/114) and 14 rows per segment are computed twice.
-constexpr int FI_TW = 114, FI_M = 7, FI_MC = 128, FI_G = 4, FI_RING = 20, FI_THREADS = 512;
-constexpr int FI_MROW = 5 * FI_MC;                       // floats per ring row
-__device__ __forceinline__ int fi_vidx(int c) { return (c >> 1) + (c & 1) * (FI_MC / 2); }   // even | odd columns
+// Measured on MI355X (in-kernel stamps, 1080p): a step costs ~2.9k cycles in A (bound by the CU's share
+// of HBM bandwidth: 49 KB of expansion samples per step and CU), ~1.4k in B, ~2.7k in C.  Shapes that
+// were tried and were slower: 64-column strips (4 blocks per CU, more halo), software-pipelined or
+// wave-specialised loads (the CU's memory pipe, not latency, bounds A), one output per thread in C.
+constexpr int FI_M = 7, FI_MC = 128, FI_G = 4, FI_TW = FI_MC - 2 * FI_M, FI_THREADS = FI_MC * FI_G;
+constexpr int FI_RING = FI_G + 16, FI_MROW = 5 * FI_MC, FI_HALF = FI_MC / 2;
 
-__global__ __launch_bounds__(FI_THREADS) void flow_iter_kernel(const float *R, const float2 *flow_in, float2 *flow_out,
-                                                               int h, int w, int seg_rows)
+__global__ __launch_bounds__(FI_THREADS, 4) void flow_iter_kernel(const float *R, const float2 *flow_in, float2 *flow_out,
+                                                                  int h, int w, int seg_rows)
 {
     __shared__ float s_m[FI_RING * FI_MROW];             // [slot][ch][c]
-    __shared__ double s_v[5 * FI_G * FI_MC];             // [ch][r][vidx(c)]
+    __shared__ double s_v[5 * FI_G * FI_MC];             // [ch][r][even columns | odd columns]
     const int tid = threadIdx.x;
     const int x0 = blockIdx.x * FI_TW;
     const int ys = blockIdx.y * seg_rows;
@@ -480,37 +490,46 @@ __global__ __launch_bounds__(FI_THREADS) void flow_iter_kernel(const float *R, c
     const int ye = min(h, ys + seg_rows);
     const size_t p = blockIdx.z;
     const size_t P = (size_t)h * w;
-    const float *R0 = R + p * 5 * P, *R1 = R0 + 5 * P;
+    const __amdgpu_buffer_rsrc_t rR = ipx_make_rsrc(R + p * 5 * P, (unsigned)(10 * P * 4));
+    const unsigned P4 = (unsigned)(P * 4);
     const float2 *fin = flow_in + p * P;
     float2 *fout = flow_out + p * P;
 
     const int ac = tid & (FI_MC - 1), ar = tid >> 7;     // phase A: column, row within the group
     int ax = x0 - FI_M + ac;
     ax = ax < 0 ? 0 : (ax > w - 1 ? w - 1 : ax);
-    // matrix row j (unclamped) lives in ring slot (j - ys + 8) % 20
-    auto fill_row = [&](int j) {
-        const int y = j < 0 ? 0 : (j > h - 1 ? h - 1 : j);
+    auto clamp_row = [&](int j) { return j < 0 ? 0 : (j > h - 1 ? h - 1 : j); };
+    // matrix row j (unclamped) lives in ring slot (j - ys + 8) % RING
+    auto fill_row = [&](int j, float2 d) {
+        UmIn in;
         float m[5];
-        update_matrix_px(R0, R1, fin, ax, y, h, w, P, m);
+        um_load(rR, P4, d, ax, clamp_row(j), h, w, in);
+        um_finish(in, d, ax, clamp_row(j), h, w, m);
         float *dst = s_m + ((j - ys + 8) % FI_RING) * FI_MROW + ac;
 #pragma unroll
         for (int ch = 0; ch < 5; ++ch) dst[ch * FI_MC] = m[ch];
     };
-    // phase B items: (ch = tid >> 7, c = tid & 127) for every thread, (ch = 4, c = tid) for tid < 128
-    const float *col0 = s_m + (tid >> 7) * FI_MC + ac;
+    // phase B items: (ch = tid >> 7, c = ac) for every thread, (ch = 4, c = tid) for tid < 128
+    const float *col0 = s_m + ar * FI_MC + ac;
     const float *col1 = s_m + 4 * FI_MC + ac;
-    double *vo0 = s_v + (tid >> 7) * (FI_G * FI_MC) + fi_vidx(ac);
-    double *vo1 = s_v + 4 * (FI_G * FI_MC) + fi_vidx(ac);
+    const int vi = (ac >> 1) + (ac & 1) * FI_HALF;
+    double *vo0 = s_v + ar * (FI_G * FI_MC) + vi;
+    double *vo1 = s_v + 4 * (FI_G * FI_MC) + vi;
     const bool has1 = tid < FI_MC;
     double v0 = 0.0, v1 = 0.0;
 
 #pragma unroll 1
-    for (int j = ys - FI_M + ar; j < ys + FI_M; j += FI_G) fill_row(j);    // rows ys-7 .. ys+6
+    for (int j = ys - FI_M + ar; j < ys + FI_M; j += FI_G) fill_row(j, fin[(size_t)clamp_row(j) * w + ax]);   // rows ys-7 .. ys+6
     int slot_in = 15 % FI_RING;                          // slot of row yb+7 for yb = ys
     int slot_out = 1;                                    // slot of row ys-7, the first row to leave the window
+    float2 dcur = fin[(size_t)clamp_row(ys + FI_M + ar) * w + ax];
+    float2 dnext = fin[(size_t)clamp_row(ys + FI_G + FI_M + ar) * w + ax];
 #pragma unroll 1
     for (int yb = ys; yb < ye; yb += FI_G) {
-        fill_row(yb + FI_M + ar);                        // rows yb+7 .. yb+10
+        const int jr = yb + FI_M + ar;                   // this thread's new matrix row: rows yb+7 .. yb+10
+        fill_row(jr, dcur);
+        dcur = dnext;
+        dnext = fin[(size_t)clamp_row(jr + 2 * FI_G) * w + ax];   // flow vector two steps ahead
         __syncthreads();
         if (yb == ys) {                                  // first output row: direct 15-row sum
             for (int i = 1; i <= 2 * FI_M; ++i) {        // rows ys-7 .. ys+6 = slots 1 .. 14
@@ -533,29 +552,35 @@ __global__ __launch_bounds__(FI_THREADS) void flow_iter_kernel(const float *R, c
             if (has1) vo1[r * FI_MC] = v1;
         }
         __syncthreads();
-        // horizontal sums + solve: waves 0..3, thread -> row r = tid >> 6, outputs 2l, 2l+1 (l < 57)
-        if (tid < 64 * FI_G) {
+        // horizontal sums + solve: thread -> row r = tid >> 6, outputs 2l, 2l+1 (l < 57)
+        if (tid < FI_HALF * FI_G) {
             const int r = tid >> 6, l = tid & 63;
             const int y = yb + r;
             if (l < FI_TW / 2 && y < ye) {
-                double acc[5][2];
+                // window of output 2l = matrix columns 2l .. 2l+14; even columns at [l + i], odd at [HALF + l + i]
+                double acc[5];
 #pragma unroll
                 for (int ch = 0; ch < 5; ++ch) {
-                    // window of output 2l = matrix columns 2l .. 2l+14; even columns at [l + i], odd at [64 + l + i]
                     const double *ve = s_v + ch * (FI_G * FI_MC) + r * FI_MC + l;
-                    const double *vd = ve + FI_MC / 2;
+                    const double *vd = ve + FI_HALF;
                     double s = ve[0];
 #pragma unroll
                     for (int i = 1; i <= FI_M; ++i) s += vd[i - 1] + ve[i];
-                    acc[ch][0] = s;
-                    acc[ch][1] = s + (vd[FI_M] - ve[0]);
+                    acc[ch] = s;
                 }
                 const double scale = 1.0 / (double)((2 * FI_M + 1) * (2 * FI_M + 1));
                 float2 o[2];
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
-                    const double g11 = acc[0][j] * scale, g12 = acc[1][j] * scale, g22 = acc[2][j] * scale,
-                                 h1 = acc[3][j] * scale, h2 = acc[4][j] * scale;
+                    if (j == 1) {                        // slide the window by one column: + column 2l+15, - column 2l
+#pragma unroll
+                        for (int ch = 0; ch < 5; ++ch) {
+                            const double *ve = s_v + ch * (FI_G * FI_MC) + r * FI_MC + l;
+                            acc[ch] += ve[FI_HALF + FI_M] - ve[0];
+                        }
+                    }
+                    const double g11 = acc[0] * scale, g12 = acc[1] * scale, g22 = acc[2] * scale,
+                                 h1 = acc[3] * scale, h2 = acc[4] * scale;
                     const double idet = 1. / (g11 * g22 - g12 * g12 + 1e-3);
                     o[j].x = (float)((g11 * h2 - g12 * h1) * idet);
                     o[j].y = (float)((g22 * h1 - g12 * h2) * idet);
@@ -887,3 +912,4 @@ extern "C" int ipx_farneback_pair(ipx_ctx *ctx, const float *prev, const float *
     IPX_CHECK_HIP(hipMemcpyAsync(flow, uv, P * sizeof(float2), hipMemcpyDeviceToDevice, ctx->stream));
     return IPX_OK;
 }
+
