@@ -118,27 +118,39 @@ def main():
             own = torch.cat(parts).contiguous()
         chunks.append(own)
 
-    def step(i):
+    def submit(i):
+        """Enqueue step i; returns a callable that completes it (copy-back + the host's float glue)."""
         fr = chunks[i % 2]
         if world == 1:
-            return eng.detect_chunk(fr)
+            return eng.detect_chunk_async(fr).result
         out = sharding.detect_chunk_sharded(eng, fr, a, b, n_total, comm)
-        return sharding.results_to_host(out, H * W)
+        return lambda: sharding.results_to_host(out, H * W)
+
+    def run(first, count):
+        """`count` steps, software-pipelined as a chunk driver would: step k+1 is on the GPU while the host
+        finishes step k.  Every step's results are produced inside the call."""
+        res, pending = None, None
+        for i in range(first, first + count):
+            nxt = submit(i)
+            if pending is not None:
+                res = pending()
+            pending = nxt
+        if pending is not None:
+            res = pending()
+        return res
 
     def fence():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for i in range(args.warmup):
-        step(i)
+    run(0, args.warmup)
     if not args.no_profile:
         eng.profile_enable(True)
         eng.profile_reset()
     fence()
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        res = step(args.warmup + i)
+    res = run(args.warmup, args.steps)
     fence()
     dt = time.perf_counter() - t0
     prof = {} if args.no_profile else eng.profile_read()

@@ -255,6 +255,14 @@ class Engine:
                                    _ptr(keep), _ptr(counts), _ptr(cluster), _ptr(fin)))
         return dict(flows=flows, keep=keep, counts=counts, cluster=cluster, final_bits=fin)
 
+    def detect_chunk_async(self, frames):
+        """Enqueue the whole path and the copy-back of its per-frame integers (on a side stream into pinned
+        host memory); returns a handle whose ``result()`` waits for THIS chunk only, so a driver can submit
+        chunk k+1 before it post-processes chunk k (the GPU never idles on the host's float glue)."""
+        if not torch.is_tensor(frames):
+            frames = self.to_device(frames, np.uint8)
+        return _PendingChunk(self, frames)
+
     def detect_chunk(self, frames, want_masks=False):
         """frames: (n,H,W) uint8 numpy array or device tensor -> dict with the four float64 arrays
         of ip.py:632 (``total_counts, cluster_counts, avg_sizes, avg_brightnesses``), ``flows``
@@ -273,4 +281,39 @@ class Engine:
         if want_masks:
             m = self.unpack_mask(d["final_bits"], H, W).cpu().numpy().astype(bool)
             out["final_masks"] = [m[i] if keep[i] else None for i in range(n)]
+        return out
+
+
+class _PendingChunk:
+    def __init__(self, eng, frames):
+        n, H, W = frames.shape
+        self.n_pixels = H * W
+        self.dev = eng.detect_chunk_device(frames)
+        self.frames = frames                               # keep inputs and outputs alive until the copies land
+        main = torch.cuda.current_stream(eng.device)
+        if getattr(eng, "_copy_stream", None) is None:
+            eng._copy_stream = torch.cuda.Stream(eng.device)
+        done = torch.cuda.Event()
+        done.record(main)
+        self.host = {}
+        with torch.cuda.stream(eng._copy_stream):
+            eng._copy_stream.wait_event(done)
+            for k in ("keep", "counts", "cluster", "flows"):
+                t = self.dev[k]
+                h = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+                h.copy_(t, non_blocking=True)
+                self.host[k] = h
+            self.ready = torch.cuda.Event()
+            self.ready.record(eng._copy_stream)
+
+    def result(self):
+        self.ready.synchronize()
+        keep = self.host["keep"].numpy()
+        counts = self.host["counts"].numpy()
+        cluster = self.host["cluster"].numpy()
+        total, cc, cs, cb = hostmath.chunk_results(keep, counts, cluster, self.n_pixels)
+        out = dict(total_counts=total, cluster_counts=cc, avg_sizes=cs, avg_brightnesses=cb,
+                   flows=self.host["flows"].numpy().astype(np.float64), keep=keep.copy(), counts=counts.copy(),
+                   cluster=cluster.copy())
+        self.dev = self.frames = None
         return out

@@ -154,3 +154,19 @@ def test_chunk_is_deterministic_and_matches_stagewise(eng):
     cl, _ = eng.cluster_stats(fd, fin, keep)
     assert bool((fin == a["final_bits"]).all()) and bool((cl == a["cluster"]).all())
     assert bool((a["counts"][:, :3] == c3).all()) and bool((a["counts"][:, 3:] == dense).all())
+
+
+def test_async_chunks_overlap_and_match(eng):
+    """Two chunks in flight at once (different shapes, so the scratch arenas regrow between them): each
+    handle returns exactly what the blocking call returns."""
+    from image_processing_amd import synth
+    fa = synth.chunk_numpy(5, 18, 96, 128, motion_at=(4,), hot=14.0, stuck=3)
+    fb = synth.chunk_numpy(6, 11, 131, 203, hot=10.0, blobs=4)
+    pa = eng.detect_chunk_async(fa)
+    pb = eng.detect_chunk_async(fb)
+    ra, rb = pa.result(), pb.result()
+    for got, frames in ((ra, fa), (rb, fb)):
+        ref = eng.detect_chunk(frames)
+        for k in ("total_counts", "cluster_counts", "avg_sizes", "avg_brightnesses", "flows"):
+            assert _eq_nan(got[k], ref[k]), k
+        assert np.array_equal(got["keep"], ref["keep"]) and np.array_equal(got["counts"], ref["counts"])
