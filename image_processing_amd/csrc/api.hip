@@ -171,7 +171,7 @@ extern "C" int ipx_timer_end(ipx_ctx *ctx, float *elapsed_ms)
 
 // ---- built-in profiler ----------------------------------------------------------------------
 static const char *const g_kid_names[KID_COUNT] = {
-    "pyr_level", "polyexp", "flow_upsample", "flow_iter", "magnitude",
+    "pyr_level", "polyexp", "flow_iter",
     "detect", "damaged_mask",
     "ccl_init", "ccl_merge", "ccl_reduce", "ccl_select", "close_cross3", "cluster_eval",
     "persistent", "static_maps", "static_from_maps", "finalize", "misc",

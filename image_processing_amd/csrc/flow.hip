@@ -350,32 +350,6 @@ __global__ __launch_bounds__(256) void polyexp_kernel(const float *I, int h, int
     o[4 * P] = (float)(b6 * pc.ig55);
 }
 
-// flow of the next finer level = linear resize of the coarser flow, times 1/pyr_scale (= 2)
-__global__ void flow_upsample_kernel(const float2 *src, int sh, int sw, float2 *dst, int dh, int dw,
-                                     const int *x_ofs, const float *x_a, const int *y_ofs, const float *y_b)
-{
-    const int dx = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int dy = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (dx >= dw || dy >= dh) return;
-    const size_t p = blockIdx.z;
-    const float2 *S0 = src + (p * sh + y_ofs[2 * dy]) * (size_t)sw;
-    const float2 *S1 = src + (p * sh + y_ofs[2 * dy + 1]) * (size_t)sw;
-    const int sx = x_ofs[dx];
-    const float a1 = x_a[dx], a0 = 1.f - a1, b1 = y_b[dy], b0 = 1.f - b1;
-    float2 h0, h1;
-    if (sx >= sw - 1) {
-        h0 = S0[sx]; h1 = S1[sx];
-    } else {
-        const float2 p00 = S0[sx], p01 = S0[sx + 1], p10 = S1[sx], p11 = S1[sx + 1];
-        h0.x = p00.x * a0 + p01.x * a1; h0.y = p00.y * a0 + p01.y * a1;
-        h1.x = p10.x * a0 + p11.x * a1; h1.y = p10.y * a0 + p11.y * a1;
-    }
-    float2 o;
-    o.x = (h0.x * b0 + h1.x * b1) * 2.0f;
-    o.y = (h0.y * b0 + h1.y * b1) * 2.0f;
-    dst[(p * dh + dy) * (size_t)dw + dx] = o;
-}
-
 // FarnebackUpdateMatrices at one pixel: the five entries (G11, G12, G22, h1, h2) from the
 // expansions R0 (at the pixel) and R1 (bilinear sample at pixel + flow), with border damping.
 // Split into the loads and the arithmetic so that a caller can keep the loads in flight.
@@ -478,22 +452,51 @@ __device__ __forceinline__ void um_finish(const UmIn &in, float2 d, int x, int y
 constexpr int FI_M = 7, FI_MC = 128, FI_G = 4, FI_TW = FI_MC - 2 * FI_M, FI_THREADS = FI_MC * FI_G;
 constexpr int FI_RING = FI_G + 16, FI_MROW = 5 * FI_MC, FI_HALF = FI_MC / 2;
 
-__global__ __launch_bounds__(FI_THREADS, 4) void flow_iter_kernel(const float *R, const float2 *flow_in, float2 *flow_out,
-                                                                  int h, int w, int seg_rows)
+// Where the flow vectors of an iteration come from / go to.  IN: 0 = flow_in of the same level, 1 = zero
+// (first iteration of the coarsest level), 2 = linear resize x2 of the coarser level's flow, evaluated in
+// place of a separate upsampling pass (flow of a level = linear resize of the coarser flow, times 1/pyr_scale = 2).  REDUCE: the
+// last level-0 iteration of the metric path does not store the field at all; it accumulates the f32
+// magnitudes (ip.py:868) into one f64 partial per workgroup.
+struct FiArgs {
+    const float *R;
+    const float2 *flow_in;      // IN 0: [np][h][w]; IN 2: the coarser field [np][sh][sw]
+    float2 *flow_out;
+    double *partial;            // REDUCE: [np][strips * nseg]
+    int h, w, seg_rows, strips, nseg, np, ppx;
+    int sh, sw;
+    const int *x_ofs, *y_ofs;
+    const float *x_a, *y_b;
+};
+
+struct FiVec {                  // a flow vector in flight: IN 0 uses p00 only
+    float2 p00, p01, p10, p11;
+    float b1;
+};
+
+template <int IN, bool REDUCE>
+__global__ __launch_bounds__(FI_THREADS, 4) void flow_iter_kernel(const FiArgs a)
 {
     __shared__ float s_m[FI_RING * FI_MROW];             // [slot][ch][c]
     __shared__ double s_v[5 * FI_G * FI_MC];             // [ch][r][even columns | odd columns]
+    const float *R = a.R;
+    const int h = a.h, w = a.w, seg_rows = a.seg_rows, strips = a.strips, np = a.np, ppx = a.ppx;
     const int tid = threadIdx.x;
-    const int x0 = blockIdx.x * FI_TW;
-    const int ys = blockIdx.y * seg_rows;
-    if (ys >= h) return;
+    // Workgroups go round-robin over the 8 XCDs (id % 8) and every XCD has its own L2.  XCD x gets the
+    // pairs [x*ppx, (x+1)*ppx), and its resident workgroups are the same strip/segment of consecutive
+    // pairs, then the neighbouring strips: the expansion of frame p+1 (sampled by pair p, read in place by
+    // pair p+1) and the column halo shared by two strips are then fetched once per L2 instead of twice.
+    const int xcd = blockIdx.x & 7, k = blockIdx.x >> 3;
+    const int pl = k % ppx, t = k / ppx;
+    const int x0 = (t % strips) * FI_TW;
+    const int ys = (t / strips) * seg_rows;
+    const size_t p = (size_t)xcd * ppx + pl;
+    if (ys >= h || p >= (size_t)np) return;
     const int ye = min(h, ys + seg_rows);
-    const size_t p = blockIdx.z;
     const size_t P = (size_t)h * w;
     const __amdgpu_buffer_rsrc_t rR = ipx_make_rsrc(R + p * 5 * P, (unsigned)(10 * P * 4));
     const unsigned P4 = (unsigned)(P * 4);
-    const float2 *fin = flow_in + p * P;
-    float2 *fout = flow_out + p * P;
+    const float2 *fin = a.flow_in + p * (IN == 2 ? (size_t)a.sh * a.sw : P);
+    float2 *fout = a.flow_out + p * P;
 
     const int ac = tid & (FI_MC - 1), ar = tid >> 7;     // phase A: column, row within the group
     int ax = x0 - FI_M + ac;
@@ -518,18 +521,51 @@ __global__ __launch_bounds__(FI_THREADS, 4) void flow_iter_kernel(const float *R
     const bool has1 = tid < FI_MC;
     double v0 = 0.0, v1 = 0.0;
 
+    // flow vector of pixel (ax, row): the loads (vec_issue) are kept in flight across a whole step
+    int usx = 0, usx1 = 0; float ua1 = 0.f; bool uedge = false;
+    if (IN == 2) {
+        usx = a.x_ofs[ax]; ua1 = a.x_a[ax];
+        uedge = usx >= a.sw - 1;
+        usx1 = uedge ? usx : usx + 1;
+    }
+    auto vec_issue = [&](int row) {
+        FiVec v;
+        if (IN == 0) {
+            v.p00 = fin[(size_t)row * w + ax];
+        } else if (IN == 2) {
+            const float2 *S0 = fin + (size_t)a.y_ofs[2 * row] * a.sw, *S1 = fin + (size_t)a.y_ofs[2 * row + 1] * a.sw;
+            v.b1 = a.y_b[row];
+            v.p00 = S0[usx]; v.p01 = S0[usx1]; v.p10 = S1[usx]; v.p11 = S1[usx1];
+        }
+        return v;
+    };
+    auto vec_finish = [&](const FiVec &v) {
+        if (IN == 0) return v.p00;
+        if (IN == 1) return make_float2(0.f, 0.f);
+        float2 h0 = v.p00, h1 = v.p10, o;
+        if (!uedge) {
+            const float a1 = ua1, a0 = 1.f - a1;
+            h0.x = v.p00.x * a0 + v.p01.x * a1; h0.y = v.p00.y * a0 + v.p01.y * a1;
+            h1.x = v.p10.x * a0 + v.p11.x * a1; h1.y = v.p10.y * a0 + v.p11.y * a1;
+        }
+        const float b1 = v.b1, b0 = 1.f - b1;
+        o.x = (h0.x * b0 + h1.x * b1) * 2.0f;
+        o.y = (h0.y * b0 + h1.y * b1) * 2.0f;
+        return o;
+    };
 #pragma unroll 1
-    for (int j = ys - FI_M + ar; j < ys + FI_M; j += FI_G) fill_row(j, fin[(size_t)clamp_row(j) * w + ax]);   // rows ys-7 .. ys+6
+    for (int j = ys - FI_M + ar; j < ys + FI_M; j += FI_G) fill_row(j, vec_finish(vec_issue(clamp_row(j))));   // rows ys-7 .. ys+6
     int slot_in = 15 % FI_RING;                          // slot of row yb+7 for yb = ys
     int slot_out = 1;                                    // slot of row ys-7, the first row to leave the window
-    float2 dcur = fin[(size_t)clamp_row(ys + FI_M + ar) * w + ax];
-    float2 dnext = fin[(size_t)clamp_row(ys + FI_G + FI_M + ar) * w + ax];
+    FiVec dcur = vec_issue(clamp_row(ys + FI_M + ar));
+    FiVec dnext = vec_issue(clamp_row(ys + FI_G + FI_M + ar));
+    double msum = 0.0;
 #pragma unroll 1
     for (int yb = ys; yb < ye; yb += FI_G) {
         const int jr = yb + FI_M + ar;                   // this thread's new matrix row: rows yb+7 .. yb+10
-        fill_row(jr, dcur);
+        fill_row(jr, vec_finish(dcur));
         dcur = dnext;
-        dnext = fin[(size_t)clamp_row(jr + 2 * FI_G) * w + ax];   // flow vector two steps ahead
+        dnext = vec_issue(clamp_row(jr + 2 * FI_G));     // flow vector two steps ahead
         __syncthreads();
         if (yb == ys) {                                  // first output row: direct 15-row sum
             for (int i = 1; i <= 2 * FI_M; ++i) {        // rows ys-7 .. ys+6 = slots 1 .. 14
@@ -586,44 +622,39 @@ __global__ __launch_bounds__(FI_THREADS, 4) void flow_iter_kernel(const float *R
                     o[j].y = (float)((g22 * h1 - g12 * h2) * idet);
                 }
                 const int x = x0 + 2 * l;
-                float2 *dst = fout + (size_t)y * w + x;
-                if (x + 1 < w && ((w & 1) == 0)) {
-                    *reinterpret_cast<float4 *>(dst) = make_float4(o[0].x, o[0].y, o[1].x, o[1].y);
+                if (REDUCE) {
+                    if (x < w) msum += (double)sqrtf(o[0].x * o[0].x + o[0].y * o[0].y);      // cartToPolar magnitude in f32
+                    if (x + 1 < w) msum += (double)sqrtf(o[1].x * o[1].x + o[1].y * o[1].y);
                 } else {
-                    if (x < w) dst[0] = o[0];
-                    if (x + 1 < w) dst[1] = o[1];
+                    float2 *dst = fout + (size_t)y * w + x;
+                    if (x + 1 < w && ((w & 1) == 0)) {
+                        *reinterpret_cast<float4 *>(dst) = make_float4(o[0].x, o[0].y, o[1].x, o[1].y);
+                    } else {
+                        if (x < w) dst[0] = o[0];
+                        if (x + 1 < w) dst[1] = o[1];
+                    }
                 }
             }
         }
         // the next step's fill_row only writes ring rows that this step no longer reads, and the
         // barrier after it orders this step's s_v reads before the next step's s_v writes
     }
-}
-
-// mean magnitude: per-pair partial sums (f64) in a fixed order, then one finishing block per pair
-constexpr int RED_BLOCKS = 64;
-__global__ __launch_bounds__(256) void magnitude_partial_kernel(const float2 *flow, size_t P, double *partial)
-{
-    __shared__ double s_w[4];
-    const size_t p = blockIdx.y;
-    const float2 *f = flow + p * P;
-    double s = 0.0;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < P; i += (size_t)RED_BLOCKS * 256) {
-        const float2 v = f[i];
-        s += (double)sqrtf(v.x * v.x + v.y * v.y);      // cartToPolar magnitude in f32, ip.py:868
+    if (REDUCE) {                                        // fixed-order sum of the workgroup's magnitudes
+        for (int off = 32; off > 0; off >>= 1) msum += __shfl_down(msum, off);
+        __syncthreads();
+        if ((tid & 63) == 0) s_v[tid >> 6] = msum;
+        __syncthreads();
+        if (tid == 0) a.partial[p * (size_t)(strips * a.nseg) + t] = (s_v[0] + s_v[1]) + (s_v[2] + s_v[3]);
     }
-    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off);
-    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = s;
-    __syncthreads();
-    if (threadIdx.x == 0) partial[p * RED_BLOCKS + blockIdx.x] = (s_w[0] + s_w[1]) + (s_w[2] + s_w[3]);
 }
 
-__global__ void magnitude_finish_kernel(const double *partial, size_t P, int npairs, double thr, float *flows, uint8_t *keep)
+// mean magnitude: the per-workgroup partial sums (f64) of the last iteration, added in a fixed order
+__global__ void magnitude_finish_kernel(const double *partial, int nparts, size_t P, int npairs, double thr, float *flows, uint8_t *keep)
 {
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= npairs) return;
     double s = 0.0;
-    for (int i = 0; i < RED_BLOCKS; ++i) s += partial[(size_t)p * RED_BLOCKS + i];
+    for (int i = 0; i < nparts; ++i) s += partial[(size_t)p * nparts + i];
     const float m = (float)(s / (double)P);                // np.mean of an f32 array is f32
     flows[p] = m;
     if (keep) keep[p] = (double)m <= thr;                  // ip.py:559 (NaN compares false: discarded)
@@ -752,8 +783,6 @@ int build_plan(ipx_ctx *ctx, int H, int W)
     return IPX_OK;
 }
 
-inline dim3 grid64x4(int w, int h, int z) { return dim3((w + 63) / 64, (h + 3) / 4, z); }
-
 // Level image + polynomial expansion of launch frames [0, nf) (chunk frames first..first+nf-1).
 int launch_level_expansion(ipx_ctx *ctx, const LevelGeom &g, const uint8_t *frames, const uint8_t *extra, int first,
                            int nf, float *I, float *R)
@@ -781,8 +810,33 @@ int launch_level_expansion(ipx_ctx *ctx, const LevelGeom &g, const uint8_t *fram
     return IPX_OK;
 }
 
-// Flow fields of `np` pairs; pair p = launch frames (p, p+1).  Result: level-0 flow in uv_out.
-int run_pairs(ipx_ctx *ctx, const uint8_t *frames, const uint8_t *extra, int first, int np, float2 **uv_out)
+// Rows of a level are cut into segments so that a launch has a few thousand workgroups.
+struct FiGeom { int strips, nseg, seg_rows, ppx; };
+FiGeom fi_geometry(const LevelGeom &g, int np)
+{
+    FiGeom f;
+    f.strips = (g.lw + FI_TW - 1) / FI_TW;
+    int nseg = (4096 + f.strips * np - 1) / (f.strips * np);
+    const int max_seg = (g.lh + 63) / 64;
+    if (nseg > max_seg) nseg = max_seg;
+    if (nseg < 1) nseg = 1;
+    int seg_rows = (g.lh + nseg - 1) / nseg;
+    f.seg_rows = (seg_rows + FI_G - 1) / FI_G * FI_G;
+    f.nseg = (g.lh + f.seg_rows - 1) / f.seg_rows;
+    f.ppx = (np + 7) / 8;                                   // pairs per XCD
+    return f;
+}
+
+// partial magnitude sums per pair of run_pairs(..., uv_out = nullptr, partial)
+int fi_partials(const ipx_flow_plan *pl, int np)
+{
+    const FiGeom f = fi_geometry(pl->lv[0], np);
+    return f.strips * f.nseg;
+}
+
+// Flow of `np` pairs; pair p = launch frames (p, p+1).  Either the level-0 field (*uv_out) or, when
+// uv_out is null, `fi_partials` partial sums of its magnitudes per pair in `partial`.
+int run_pairs(ipx_ctx *ctx, const uint8_t *frames, const uint8_t *extra, int first, int np, float2 **uv_out, double *partial)
 {
     const ipx_flow_plan *pl = ctx->flow_plan;
     const int nf = np + 1;
@@ -790,43 +844,41 @@ int run_pairs(ipx_ctx *ctx, const uint8_t *frames, const uint8_t *extra, int fir
     void *pyr, *uv;
     IPX_TRY(ipx_scratch(ctx, SLOT_FLOW_PYR, (size_t)nf * P0 * 6 * sizeof(float) + 512, &pyr));
     IPX_TRY(ipx_scratch(ctx, SLOT_FLOW_UV, 2 * (size_t)np * P0 * sizeof(float2) + 512, &uv));
-    // two flow buffers: X receives the initial flow of a level (zeros / upsampled), the three
-    // iterations go X -> Y -> X -> Y, so a level's result is always in Y and the next level's
-    // upsampling reads Y and writes X
-    float2 *X = (float2 *)uv, *Y = X + ipx_align_up((size_t)np * P0, 32);
-    bool have_prev = false;
-    const dim3 block(256);
+    // two flow buffers, every iteration reads `cur` and writes `other`; the first iteration of a level
+    // reads the coarser level's result (or nothing at the coarsest level)
+    float2 *cur = (float2 *)uv, *other = cur + ipx_align_up((size_t)np * P0, 32);
     for (int k = pl->levels; k >= 0; --k) {
         const LevelGeom &g = pl->lv[k];
         const size_t P = (size_t)g.lh * g.lw;
         float *I = (float *)pyr, *R = I + ipx_align_up((size_t)nf * P, 64);
         IPX_TRY(launch_level_expansion(ctx, g, frames, extra, first, nf, I, R));
-        if (!have_prev) {
-            IPX_CHECK_HIP(hipMemsetAsync(X, 0, (size_t)np * P * sizeof(float2), ctx->stream));
-        } else {
-            const LevelGeom &c = pl->lv[k + 1];
-            IPX_LAUNCH(ctx, KID_UPSAMPLE, 8.0 * np * ((double)g.lh * g.lw + (double)c.lh * c.lw), flow_upsample_kernel,
-                       grid64x4(g.lw, g.lh, np), block, Y, c.lh, c.lw, X, g.lh, g.lw, g.ux_ofs, g.ux_a, g.uy_ofs, g.uy_b);
-        }
-        // segments of rows per strip so that a launch has a few thousand blocks
-        const int strips = (g.lw + FI_TW - 1) / FI_TW;
-        int nseg = (4096 + strips * np - 1) / (strips * np);
-        const int max_seg = (g.lh + 63) / 64;
-        if (nseg > max_seg) nseg = max_seg;
-        if (nseg < 1) nseg = 1;
-        int seg_rows = (g.lh + nseg - 1) / nseg;
-        seg_rows = (seg_rows + FI_G - 1) / FI_G * FI_G;
-        nseg = (g.lh + seg_rows - 1) / seg_rows;
-        const dim3 fgrid(strips, nseg, np), fblock(FI_THREADS);
+        const FiGeom f = fi_geometry(g, np);
+        const dim3 fgrid(8 * f.ppx * f.strips * f.nseg), fblock(FI_THREADS);
+        FiArgs a;
+        a.R = R; a.partial = partial;
+        a.h = g.lh; a.w = g.lw; a.seg_rows = f.seg_rows; a.strips = f.strips; a.nseg = f.nseg; a.np = np; a.ppx = f.ppx;
+        a.sh = a.sw = 0; a.x_ofs = a.y_ofs = nullptr; a.x_a = a.y_b = nullptr;
         for (int it = 0; it < 3; ++it) {                            // ip.py:864 iterations=3
-            const float2 *src = (it & 1) ? Y : X;
-            float2 *dst = (it & 1) ? X : Y;
-            IPX_LAUNCH(ctx, KID_FLOW_ITER, 56.0 * np * P, flow_iter_kernel, fgrid, fblock, R, src, dst, g.lh, g.lw, seg_rows);
+            a.flow_in = cur; a.flow_out = other;
+            const bool reduce = !uv_out && k == 0 && it == 2;
+            double bytes = 40.0 * P + (reduce ? 0.0 : 8.0 * P);
+            if (it > 0) {
+                bytes += 8.0 * P;
+                if (reduce) IPX_LAUNCH(ctx, KID_FLOW_ITER, bytes * np, (flow_iter_kernel<0, true>), fgrid, fblock, a);
+                else IPX_LAUNCH(ctx, KID_FLOW_ITER, bytes * np, (flow_iter_kernel<0, false>), fgrid, fblock, a);
+            } else if (k == pl->levels) {
+                IPX_LAUNCH(ctx, KID_FLOW_ITER, bytes * np, (flow_iter_kernel<1, false>), fgrid, fblock, a);
+            } else {
+                const LevelGeom &c = pl->lv[k + 1];
+                a.sh = c.lh; a.sw = c.lw; a.x_ofs = g.ux_ofs; a.x_a = g.ux_a; a.y_ofs = g.uy_ofs; a.y_b = g.uy_b;
+                bytes += 8.0 * c.lh * c.lw;
+                IPX_LAUNCH(ctx, KID_FLOW_ITER, bytes * np, (flow_iter_kernel<2, false>), fgrid, fblock, a);
+            }
+            float2 *t = cur; cur = other; other = t;
         }
         IPX_LAUNCH_CHECK();
-        have_prev = true;
     }
-    *uv_out = Y;
+    if (uv_out) *uv_out = cur;
     return IPX_OK;
 }
 
@@ -857,13 +909,14 @@ extern "C" int ipx_flow_metric(ipx_ctx *ctx, const uint8_t *frames, int n, int H
     if (total <= 0) { IPX_LAUNCH_CHECK(); return IPX_OK; }
     const int B = pair_batch(H, W, total);
     void *red;
-    IPX_TRY(ipx_scratch(ctx, SLOT_FLOW_RED, (size_t)B * RED_BLOCKS * sizeof(double), &red));
+    const LevelGeom &g0 = ctx->flow_plan->lv[0];             // upper bound of fi_partials for any batch size
+    const size_t max_parts = (size_t)((g0.lw + FI_TW - 1) / FI_TW) * ((g0.lh + 63) / 64);
+    IPX_TRY(ipx_scratch(ctx, SLOT_FLOW_RED, (size_t)B * max_parts * sizeof(double), &red));
     for (int i0 = first_pair; i0 < n; i0 += B) {
         const int np = n - i0 < B ? n - i0 : B;
-        float2 *uv;
-        IPX_TRY(run_pairs(ctx, frames, prev_frame, i0 - 1, np, &uv));
-        IPX_LAUNCH(ctx, KID_MAGNITUDE, 8.0 * np * P, magnitude_partial_kernel, dim3(RED_BLOCKS, np), dim3(256), uv, P, (double *)red);
-        IPX_LAUNCH(ctx, KID_MISC, 8.0 * RED_BLOCKS * np, magnitude_finish_kernel, dim3((np + 63) / 64), dim3(64), (const double *)red, P, np,
+        const int nparts = fi_partials(ctx->flow_plan, np);
+        IPX_TRY(run_pairs(ctx, frames, prev_frame, i0 - 1, np, nullptr, (double *)red));
+        IPX_LAUNCH(ctx, KID_MISC, 8.0 * nparts * np, magnitude_finish_kernel, dim3((np + 63) / 64), dim3(64), (const double *)red, nparts, P, np,
                            ctx->p.flow_threshold, flows + i0, keep ? keep + i0 : nullptr);
         IPX_LAUNCH_CHECK();
     }
@@ -908,7 +961,7 @@ extern "C" int ipx_farneback_pair(ipx_ctx *ctx, const float *prev, const float *
         return IPX_ERR_UNSUPPORTED;
     }
     float2 *uv;
-    IPX_TRY(run_pairs(ctx, u8, nullptr, 0, 1, &uv));
+    IPX_TRY(run_pairs(ctx, u8, nullptr, 0, 1, &uv, nullptr));
     IPX_CHECK_HIP(hipMemcpyAsync(flow, uv, P * sizeof(float2), hipMemcpyDeviceToDevice, ctx->stream));
     return IPX_OK;
 }

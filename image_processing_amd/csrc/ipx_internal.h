@@ -26,7 +26,7 @@ struct ipx_flow_plan;   // flow.hip
 // stream around every launch, accumulated per class together with the launch's ALGORITHMIC bytes
 // (compulsory reads + writes: every input and output array counted once; DESIGN.md lists them).
 enum ipx_kid {
-    KID_PYR = 0, KID_POLYEXP, KID_UPSAMPLE, KID_FLOW_ITER, KID_MAGNITUDE,
+    KID_PYR = 0, KID_POLYEXP, KID_FLOW_ITER,
     KID_DETECT, KID_DAMAGED_MASK,
     KID_CCL_INIT, KID_CCL_MERGE, KID_CCL_REDUCE, KID_CCL_SELECT, KID_CLOSE, KID_CLUSTER_EVAL,
     KID_PERSISTENT, KID_STATIC_MAPS, KID_STATIC_FROM_MAPS, KID_FINALIZE, KID_MISC,
