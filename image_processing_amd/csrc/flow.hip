@@ -375,7 +375,9 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t ipx_make_rsrc(const void *base
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, (int)bytes, 0x00020000);
 }
 
-// rR: the pair's expansions, R0 planes 0..4 then R1 planes 5..9, P4 = bytes per plane
+// rR: the pair's expansions, R0 planes 0..4 then R1 planes 5..9, P4 = bytes per plane.  The loads are
+// unconditional (no divergent control flow between issue and use): a sample position outside the image gets
+// an offset beyond the resource, for which the buffer load returns 0 without touching memory.
 __device__ __forceinline__ void um_load(__amdgpu_buffer_rsrc_t rR, unsigned P4, float2 d, int x, int y, int h, int w, UmIn &in)
 {
     const unsigned o4 = (unsigned)(y * w + x) * 4u;
@@ -383,15 +385,14 @@ __device__ __forceinline__ void um_load(__amdgpu_buffer_rsrc_t rR, unsigned P4, 
     const bool inb = um_position(d, x, y, h, w, x1, y1, fx, fy);
 #pragma unroll
     for (int c = 0; c < 5; ++c) in.r0[c] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rR, o4, c * P4, 0));
-    if (inb) {
-        const unsigned q0 = (unsigned)(y1 * w + x1) * 4u, q1 = q0 + (unsigned)w * 4u;
+    const unsigned q0 = inb ? (unsigned)(y1 * w + x1) * 4u : 0xfffffff0u;
+    const unsigned q1 = inb ? q0 + (unsigned)w * 4u : 0xfffffff0u;
 #pragma unroll
-        for (int c = 0; c < 5; ++c) {
-            const ipx_u32x2 a = __builtin_amdgcn_raw_buffer_load_b64(rR, q0, (5 + c) * P4, 0);
-            const ipx_u32x2 b = __builtin_amdgcn_raw_buffer_load_b64(rR, q1, (5 + c) * P4, 0);
-            in.q[c][0] = __uint_as_float(a.x); in.q[c][1] = __uint_as_float(a.y);
-            in.q[c][2] = __uint_as_float(b.x); in.q[c][3] = __uint_as_float(b.y);
-        }
+    for (int c = 0; c < 5; ++c) {
+        const ipx_u32x2 a = __builtin_amdgcn_raw_buffer_load_b64(rR, q0, (5 + c) * P4, 0);
+        const ipx_u32x2 b = __builtin_amdgcn_raw_buffer_load_b64(rR, q1, (5 + c) * P4, 0);
+        in.q[c][0] = __uint_as_float(a.x); in.q[c][1] = __uint_as_float(a.y);
+        in.q[c][2] = __uint_as_float(b.x); in.q[c][3] = __uint_as_float(b.y);
     }
 }
 
@@ -436,27 +437,31 @@ __device__ __forceinline__ void um_finish(const UmIn &in, float2 d, int x, int y
 }
 
 // One Farneback iteration, fused: FarnebackUpdateMatrices -> 15x15 box window (replicate borders,
-// f64) -> regularised 2x2 solve, flow_in -> flow_out (distinct buffers).  The matrices never
-// touch HBM.  A 512-thread block owns a strip of 114 output columns (128 matrix columns with the
-// window halo) and MARCHES down a segment of rows, 4 rows per step:
-//   A  every thread computes one matrix pixel of the 4 new rows into a 20-row LDS ring (the flow
-//      vector of the next step's pixel is already in flight);
-//   B  threads own (column, channel) items and keep the running vertical 15-row sum in an f64
+// f64) -> regularised 2x2 solve.  The matrices never touch HBM.  A 512-thread workgroup owns a strip of
+// 114 output columns (128 matrix columns with the window halo) and MARCHES down a segment of rows, 4 rows
+// per step, through a 23-row LDS ring of matrix rows.  The waves are specialised so that the memory phase
+// of one step runs under the arithmetic of the previous one:
+//   producers (waves 4-7): issue the expansion loads of the NEXT step's 4 matrix rows (two rows per
+//      thread), take part in B while they are in flight, and finish / store them into the ring during C;
+//   B  (all waves) threads own (column, channel) items and keep the running vertical 15-row sum in an f64
 //      register (+ new row - row leaving the window), writing the 4 rows of sums to LDS;
-//   C  horizontal 15-sums slide over two adjacent outputs per thread (waves 0-3), then the 2x2 solve.
-// Only the horizontal halo (128/114) and 14 rows per segment are computed twice.
-// Measured on MI355X (in-kernel stamps, 1080p): a step costs ~2.9k cycles in A (bound by the CU's share
-// of HBM bandwidth: 49 KB of expansion samples per step and CU), ~1.4k in B, ~2.7k in C.  Shapes that
-// were tried and were slower: 64-column strips (4 blocks per CU, more halo), software-pipelined or
-// wave-specialised loads (the CU's memory pipe, not latency, bounds A), one output per thread in C.
-constexpr int FI_M = 7, FI_MC = 128, FI_G = 4, FI_TW = FI_MC - 2 * FI_M, FI_THREADS = FI_MC * FI_G;
-constexpr int FI_RING = FI_G + 16, FI_MROW = 5 * FI_MC, FI_HALF = FI_MC / 2;
+//   C  (waves 0-3, one row each) horizontal 15-sums slide over two adjacent outputs per thread, then the
+//      2x2 solve and the store (or the magnitude sum).
+// Two LDS-only barriers per step; the ring is large enough (rows yb-8 .. yb+14) that the producers never
+// write a row B still reads.  79,360 bytes of LDS: two workgroups per CU.
+// Only the horizontal halo (128/114) and 18 rows per segment are computed twice.
+// Measured on MI355X (PMC, 1080p): the unspecialised form of this kernel (every wave A, then B, then C)
+// kept the VALU 45 % and the LDS 46 % busy with the waves parked 64 % of the time; it was NOT limited
+// by HBM or fabric traffic (halving the fetched bytes left its time unchanged).
+constexpr int FI_M = 7, FI_MC = 128, FI_G = 4, FI_TW = FI_MC - 2 * FI_M, FI_THREADS = 512;
+constexpr int FI_RING = 23, FI_MROW = 5 * FI_MC, FI_HALF = FI_MC / 2;
+constexpr size_t FI_LDS_BYTES = FI_RING * FI_MROW * sizeof(float) + 5 * FI_G * FI_MC * sizeof(double);
 
 // Where the flow vectors of an iteration come from / go to.  IN: 0 = flow_in of the same level, 1 = zero
 // (first iteration of the coarsest level), 2 = linear resize x2 of the coarser level's flow, evaluated in
-// place of a separate upsampling pass (flow of a level = linear resize of the coarser flow, times 1/pyr_scale = 2).  REDUCE: the
-// last level-0 iteration of the metric path does not store the field at all; it accumulates the f32
-// magnitudes (ip.py:868) into one f64 partial per workgroup.
+// place of a separate upsampling pass (flow of a level = linear resize of the coarser flow, times
+// 1/pyr_scale = 2).  REDUCE: the last level-0 iteration of the metric path does not store the field at
+// all; it accumulates the f32 magnitudes (ip.py:868) into one f64 partial per workgroup.
 struct FiArgs {
     const float *R;
     const float2 *flow_in;      // IN 0: [np][h][w]; IN 2: the coarser field [np][sh][sw]
@@ -473,14 +478,22 @@ struct FiVec {                  // a flow vector in flight: IN 0 uses p00 only
     float b1;
 };
 
+// workgroup barrier that orders LDS traffic only: global loads stay in flight across it
+__device__ __forceinline__ void fi_barrier()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 template <int IN, bool REDUCE>
 __global__ __launch_bounds__(FI_THREADS, 4) void flow_iter_kernel(const FiArgs a)
 {
-    __shared__ float s_m[FI_RING * FI_MROW];             // [slot][ch][c]
-    __shared__ double s_v[5 * FI_G * FI_MC];             // [ch][r][even columns | odd columns]
+    extern __shared__ __align__(16) unsigned char fi_lds[];
+    float *s_m = reinterpret_cast<float *>(fi_lds);                                        // [slot][ch][c]
+    double *s_v = reinterpret_cast<double *>(fi_lds + FI_RING * FI_MROW * sizeof(float));  // [ch][r][even | odd columns]
     const float *R = a.R;
     const int h = a.h, w = a.w, seg_rows = a.seg_rows, strips = a.strips, np = a.np, ppx = a.ppx;
     const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     // Workgroups go round-robin over the 8 XCDs (id % 8) and every XCD has its own L2.  XCD x gets the
     // pairs [x*ppx, (x+1)*ppx), and its resident workgroups are the same strip/segment of consecutive
     // pairs, then the neighbouring strips: the expansion of frame p+1 (sampled by pair p, read in place by
@@ -498,30 +511,17 @@ __global__ __launch_bounds__(FI_THREADS, 4) void flow_iter_kernel(const FiArgs a
     const float2 *fin = a.flow_in + p * (IN == 2 ? (size_t)a.sh * a.sw : P);
     float2 *fout = a.flow_out + p * P;
 
-    const int ac = tid & (FI_MC - 1), ar = tid >> 7;     // phase A: column, row within the group
+    const int ac = tid & (FI_MC - 1);                    // matrix column of phases A and B
     int ax = x0 - FI_M + ac;
     ax = ax < 0 ? 0 : (ax > w - 1 ? w - 1 : ax);
     auto clamp_row = [&](int j) { return j < 0 ? 0 : (j > h - 1 ? h - 1 : j); };
     // matrix row j (unclamped) lives in ring slot (j - ys + 8) % RING
-    auto fill_row = [&](int j, float2 d) {
-        UmIn in;
-        float m[5];
-        um_load(rR, P4, d, ax, clamp_row(j), h, w, in);
-        um_finish(in, d, ax, clamp_row(j), h, w, m);
+    auto ring_store = [&](int j, const float (&m)[5]) {
         float *dst = s_m + ((j - ys + 8) % FI_RING) * FI_MROW + ac;
 #pragma unroll
         for (int ch = 0; ch < 5; ++ch) dst[ch * FI_MC] = m[ch];
     };
-    // phase B items: (ch = tid >> 7, c = ac) for every thread, (ch = 4, c = tid) for tid < 128
-    const float *col0 = s_m + ar * FI_MC + ac;
-    const float *col1 = s_m + 4 * FI_MC + ac;
-    const int vi = (ac >> 1) + (ac & 1) * FI_HALF;
-    double *vo0 = s_v + ar * (FI_G * FI_MC) + vi;
-    double *vo1 = s_v + 4 * (FI_G * FI_MC) + vi;
-    const bool has1 = tid < FI_MC;
-    double v0 = 0.0, v1 = 0.0;
-
-    // flow vector of pixel (ax, row): the loads (vec_issue) are kept in flight across a whole step
+    // flow vector of pixel (ax, row): the loads (vec_issue) are kept in flight across most of a step
     int usx = 0, usx1 = 0; float ua1 = 0.f; bool uedge = false;
     if (IN == 2) {
         usx = a.x_ofs[ax]; ua1 = a.x_a[ax];
@@ -553,29 +553,47 @@ __global__ __launch_bounds__(FI_THREADS, 4) void flow_iter_kernel(const FiArgs a
         o.y = (h0.y * b0 + h1.y * b1) * 2.0f;
         return o;
     };
+
+    // rows ys-7 .. ys+10 (everything step 0 reads), all waves: wave pair i fills rows ys-7+i, +4, ...
 #pragma unroll 1
-    for (int j = ys - FI_M + ar; j < ys + FI_M; j += FI_G) fill_row(j, vec_finish(vec_issue(clamp_row(j))));   // rows ys-7 .. ys+6
-    int slot_in = 15 % FI_RING;                          // slot of row yb+7 for yb = ys
+    for (int j = ys - FI_M + (wave >> 1); j <= ys + FI_M + FI_G - 1; j += FI_G) {
+        const int y = clamp_row(j);
+        const float2 d = vec_finish(vec_issue(y));
+        UmIn in;
+        float m[5];
+        um_load(rR, P4, d, ax, y, h, w, in);
+        um_finish(in, d, ax, y, h, w, m);
+        ring_store(j, m);
+    }
+    const bool producer = wave >= 4;
+    const int prow = (wave - 4) >> 1;                    // producers: rows prow and prow + 2 of a group of 4
+    FiVec dv0, dv1;
+    if (producer) {
+        dv0 = vec_issue(clamp_row(ys + FI_M + FI_G + prow));
+        dv1 = vec_issue(clamp_row(ys + FI_M + FI_G + 2 + prow));
+    }
+    fi_barrier();
+
+    // phase B items: (ch = tid >> 7, c = ac) for every thread, (ch = 4, c = ac) for the threads of waves 4, 5
+    const float *col0 = s_m + (wave >> 1) * FI_MC + ac;
+    const float *col1 = s_m + 4 * FI_MC + ac;
+    const int vi = (ac >> 1) + (ac & 1) * FI_HALF;
+    double *vo0 = s_v + (wave >> 1) * (FI_G * FI_MC) + vi;
+    double *vo1 = s_v + 4 * (FI_G * FI_MC) + vi;
+    const bool has1 = wave == 4 || wave == 5;
+    double v0 = 0.0, v1 = 0.0;
+    for (int i = 1; i <= 2 * FI_M; ++i) {                // first output row: rows ys-7 .. ys+6 = slots 1 .. 14
+        v0 += (double)col0[i * FI_MROW];
+        if (has1) v1 += (double)col1[i * FI_MROW];
+    }
+    int slot_in = 15;                                    // slot of row yb+7 for yb = ys
     int slot_out = 1;                                    // slot of row ys-7, the first row to leave the window
-    FiVec dcur = vec_issue(clamp_row(ys + FI_M + ar));
-    FiVec dnext = vec_issue(clamp_row(ys + FI_G + FI_M + ar));
     double msum = 0.0;
-#pragma unroll 1
-    for (int yb = ys; yb < ye; yb += FI_G) {
-        const int jr = yb + FI_M + ar;                   // this thread's new matrix row: rows yb+7 .. yb+10
-        fill_row(jr, vec_finish(dcur));
-        dcur = dnext;
-        dnext = vec_issue(clamp_row(jr + 2 * FI_G));     // flow vector two steps ahead
-        __syncthreads();
-        if (yb == ys) {                                  // first output row: direct 15-row sum
-            for (int i = 1; i <= 2 * FI_M; ++i) {        // rows ys-7 .. ys+6 = slots 1 .. 14
-                v0 += (double)col0[i * FI_MROW];
-                if (has1) v1 += (double)col1[i * FI_MROW];
-            }
-        }
+
+    auto phase_b = [&](bool first_step) {
 #pragma unroll
         for (int r = 0; r < FI_G; ++r) {
-            if (yb == ys && r == 0) {
+            if (first_step && r == 0) {
                 v0 += (double)col0[slot_in * FI_MROW];
                 if (has1) v1 += (double)col1[slot_in * FI_MROW];
             } else {
@@ -587,10 +605,40 @@ __global__ __launch_bounds__(FI_THREADS, 4) void flow_iter_kernel(const FiArgs a
             vo0[r * FI_MC] = v0;
             if (has1) vo1[r * FI_MC] = v1;
         }
-        __syncthreads();
-        // horizontal sums + solve: thread -> row r = tid >> 6, outputs 2l, 2l+1 (l < 57)
-        if (tid < FI_HALF * FI_G) {
-            const int r = tid >> 6, l = tid & 63;
+    };
+
+    if (producer) {
+#pragma unroll 1
+        for (int yb = ys; yb < ye; yb += FI_G) {
+            const bool more = yb + FI_G < ye;            // the next step needs matrix rows yb+11 .. yb+14
+            const int j0 = yb + FI_M + FI_G + prow, j1 = j0 + 2;
+            if (more) {
+                UmIn in0, in1;
+                const float2 d0 = vec_finish(dv0), d1 = vec_finish(dv1);
+                um_load(rR, P4, d0, ax, clamp_row(j0), h, w, in0);
+                um_load(rR, P4, d1, ax, clamp_row(j1), h, w, in1);
+                phase_b(yb == ys);
+                fi_barrier();
+                float m[5];
+                um_finish(in0, d0, ax, clamp_row(j0), h, w, m);
+                ring_store(j0, m);
+                um_finish(in1, d1, ax, clamp_row(j1), h, w, m);
+                ring_store(j1, m);
+                dv0 = vec_issue(clamp_row(j0 + FI_G));
+                dv1 = vec_issue(clamp_row(j1 + FI_G));
+            } else {
+                phase_b(yb == ys);
+                fi_barrier();
+            }
+            fi_barrier();                                // ring rows of the next step written
+        }
+    } else {
+#pragma unroll 1
+        for (int yb = ys; yb < ye; yb += FI_G) {
+            phase_b(yb == ys);
+            fi_barrier();
+            // ---- C: horizontal sums + solve, row r = wave, outputs 2l, 2l+1 (l < 57)
+            const int r = wave, l = tid & 63;
             const int y = yb + r;
             if (l < FI_TW / 2 && y < ye) {
                 // window of output 2l = matrix columns 2l .. 2l+14; even columns at [l + i], odd at [HALF + l + i]
@@ -635,15 +683,13 @@ __global__ __launch_bounds__(FI_THREADS, 4) void flow_iter_kernel(const FiArgs a
                     }
                 }
             }
+            fi_barrier();                                // s_v free again
         }
-        // the next step's fill_row only writes ring rows that this step no longer reads, and the
-        // barrier after it orders this step's s_v reads before the next step's s_v writes
     }
     if (REDUCE) {                                        // fixed-order sum of the workgroup's magnitudes
         for (int off = 32; off > 0; off >>= 1) msum += __shfl_down(msum, off);
-        __syncthreads();
-        if ((tid & 63) == 0) s_v[tid >> 6] = msum;
-        __syncthreads();
+        if ((tid & 63) == 0) s_v[wave] = msum;
+        fi_barrier();
         if (tid == 0) a.partial[p * (size_t)(strips * a.nseg) + t] = (s_v[0] + s_v[1]) + (s_v[2] + s_v[3]);
     }
 }
@@ -779,6 +825,12 @@ int build_plan(ipx_ctx *ctx, int H, int W)
             g.uy_ofs = (const int *)(d + offs[k][6]); g.uy_b = (const float *)(d + offs[k][7]);
         }
     }
+    // the marching kernel's LDS (ring + sums) is above the 64 KB a kernel gets without asking
+    hipError_t ae = hipFuncSetAttribute((const void *)flow_iter_kernel<0, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FI_LDS_BYTES);
+    if (ae == hipSuccess) ae = hipFuncSetAttribute((const void *)flow_iter_kernel<0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FI_LDS_BYTES);
+    if (ae == hipSuccess) ae = hipFuncSetAttribute((const void *)flow_iter_kernel<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FI_LDS_BYTES);
+    if (ae == hipSuccess) ae = hipFuncSetAttribute((const void *)flow_iter_kernel<2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FI_LDS_BYTES);
+    if (ae != hipSuccess) { delete pl; ipx_set_error("hipFuncSetAttribute failed: %s", hipGetErrorString(ae)); return IPX_ERR_HIP; }
     ctx->flow_plan = pl;
     return IPX_OK;
 }
@@ -864,15 +916,15 @@ int run_pairs(ipx_ctx *ctx, const uint8_t *frames, const uint8_t *extra, int fir
             double bytes = 40.0 * P + (reduce ? 0.0 : 8.0 * P);
             if (it > 0) {
                 bytes += 8.0 * P;
-                if (reduce) IPX_LAUNCH(ctx, KID_FLOW_ITER, bytes * np, (flow_iter_kernel<0, true>), fgrid, fblock, a);
-                else IPX_LAUNCH(ctx, KID_FLOW_ITER, bytes * np, (flow_iter_kernel<0, false>), fgrid, fblock, a);
+                if (reduce) IPX_LAUNCH_LDS(ctx, KID_FLOW_ITER, bytes * np, FI_LDS_BYTES, (flow_iter_kernel<0, true>), fgrid, fblock, a);
+                else IPX_LAUNCH_LDS(ctx, KID_FLOW_ITER, bytes * np, FI_LDS_BYTES, (flow_iter_kernel<0, false>), fgrid, fblock, a);
             } else if (k == pl->levels) {
-                IPX_LAUNCH(ctx, KID_FLOW_ITER, bytes * np, (flow_iter_kernel<1, false>), fgrid, fblock, a);
+                IPX_LAUNCH_LDS(ctx, KID_FLOW_ITER, bytes * np, FI_LDS_BYTES, (flow_iter_kernel<1, false>), fgrid, fblock, a);
             } else {
                 const LevelGeom &c = pl->lv[k + 1];
                 a.sh = c.lh; a.sw = c.lw; a.x_ofs = g.ux_ofs; a.x_a = g.ux_a; a.y_ofs = g.uy_ofs; a.y_b = g.uy_b;
                 bytes += 8.0 * c.lh * c.lw;
-                IPX_LAUNCH(ctx, KID_FLOW_ITER, bytes * np, (flow_iter_kernel<2, false>), fgrid, fblock, a);
+                IPX_LAUNCH_LDS(ctx, KID_FLOW_ITER, bytes * np, FI_LDS_BYTES, (flow_iter_kernel<2, false>), fgrid, fblock, a);
             }
             float2 *t = cur; cur = other; other = t;
         }

@@ -63,6 +63,14 @@ void ipx_prof_end(ipx_ctx *ctx);
         if ((ctx)->prof.on) ipx_prof_end(ctx);                                         \
     } while (0)
 
+// Same with `lds` bytes of dynamic LDS.
+#define IPX_LAUNCH_LDS(ctx, kid, abytes, lds, kernel, grid, block, ...)                 \
+    do {                                                                               \
+        if ((ctx)->prof.on) ipx_prof_begin((ctx), (kid), (double)(abytes));            \
+        hipLaunchKernelGGL(kernel, grid, block, (lds), (ctx)->stream, __VA_ARGS__);    \
+        if ((ctx)->prof.on) ipx_prof_end(ctx);                                         \
+    } while (0)
+
 void ipx_set_error(const char *fmt, ...);
 
 #define IPX_CHECK_HIP(expr)                                                            \
