@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libipx.so")
+LIB_PATH = os.environ.get("IPX_LIB") or os.path.join(_HERE, "lib", "libipx.so")   # IPX_LIB: an instrumented build (tools/)
 
 
 class IpxError(RuntimeError):

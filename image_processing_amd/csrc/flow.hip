@@ -387,6 +387,29 @@ __device__ __forceinline__ void um_load(__amdgpu_buffer_rsrc_t rR, unsigned P4, 
     for (int c = 0; c < 5; ++c) in.r0[c] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rR, o4, c * P4, 0));
     const unsigned q0 = inb ? (unsigned)(y1 * w + x1) * 4u : 0xfffffff0u;
     const unsigned q1 = inb ? q0 + (unsigned)w * 4u : 0xfffffff0u;
+#if defined(FI_EXP) && FI_EXP == 1
+#pragma unroll
+    for (int c = 0; c < 5; ++c) {
+        const unsigned a_ = __builtin_amdgcn_raw_buffer_load_b32(rR, q0, (5 + c) * P4, 0);
+        const unsigned b_ = __builtin_amdgcn_raw_buffer_load_b32(rR, q1, (5 + c) * P4, 0);
+        in.q[c][0] = __uint_as_float(a_); in.q[c][1] = __uint_as_float(a_);
+        in.q[c][2] = __uint_as_float(b_); in.q[c][3] = __uint_as_float(b_);
+    }
+    return;
+#elif defined(FI_EXP) && FI_EXP == 2
+#pragma unroll
+    for (int c = 0; c < 5; ++c) {
+        const ipx_u32x2 a = __builtin_amdgcn_raw_buffer_load_b64(rR, o4, (c) * P4, 0);
+        const ipx_u32x2 b = __builtin_amdgcn_raw_buffer_load_b64(rR, o4, (c) * P4, 0);
+        in.q[c][0] = __uint_as_float(a.x) + q0; in.q[c][1] = __uint_as_float(a.y);
+        in.q[c][2] = __uint_as_float(b.x) + q1; in.q[c][3] = __uint_as_float(b.y);
+    }
+    return;
+#elif defined(FI_EXP) && FI_EXP == 3
+#pragma unroll
+    for (int c = 0; c < 5; ++c) { in.q[c][0] = q0; in.q[c][1] = q1; in.q[c][2] = q0; in.q[c][3] = q1; }
+    return;
+#endif
 #pragma unroll
     for (int c = 0; c < 5; ++c) {
         const ipx_u32x2 a = __builtin_amdgcn_raw_buffer_load_b64(rR, q0, (5 + c) * P4, 0);
@@ -455,7 +478,7 @@ __device__ __forceinline__ void um_finish(const UmIn &in, float2 d, int x, int y
 // by HBM or fabric traffic (halving the fetched bytes left its time unchanged).
 constexpr int FI_M = 7, FI_MC = 128, FI_G = 4, FI_TW = FI_MC - 2 * FI_M, FI_THREADS = 512;
 constexpr int FI_RING = 23, FI_MROW = 5 * FI_MC, FI_HALF = FI_MC / 2;
-constexpr size_t FI_LDS_BYTES = FI_RING * FI_MROW * sizeof(float) + 5 * FI_G * FI_MC * sizeof(double);
+constexpr size_t FI_LDS_BYTES = FI_RING * FI_MROW * sizeof(float) + 5 * FI_G * FI_MC * sizeof(double) + 16;   // + hand-off counter
 
 // Where the flow vectors of an iteration come from / go to.  IN: 0 = flow_in of the same level, 1 = zero
 // (first iteration of the coarsest level), 2 = linear resize x2 of the coarser level's flow, evaluated in
@@ -483,6 +506,15 @@ __device__ __forceinline__ void fi_barrier()
 {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
+
+#ifdef IPX_FI_STAMPS
+// Debug build only (python -m image_processing_amd.build --stamps): shader-clock totals per wave and phase
+// of every 64th workgroup, read back with ipx_debug_fi_stamps().
+__device__ unsigned long long fi_stamps[8][8];
+#define FI_STAMP(k) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); st_acc[k] += t_ - st_t; st_t = t_; } while (0)
+#else
+#define FI_STAMP(k) do { } while (0)
+#endif
 
 template <int IN, bool REDUCE>
 __global__ __launch_bounds__(FI_THREADS, 4) void flow_iter_kernel(const FiArgs a)
@@ -574,39 +606,57 @@ __global__ __launch_bounds__(FI_THREADS, 4) void flow_iter_kernel(const FiArgs a
     }
     fi_barrier();
 
-    // phase B items: (ch = tid >> 7, c = ac) for every thread, (ch = 4, c = ac) for the threads of waves 4, 5
-    const float *col0 = s_m + (wave >> 1) * FI_MC + ac;
-    const float *col1 = s_m + 4 * FI_MC + ac;
+    // phase B items (consumer waves only): column ac, channels 0-2 on waves 0-1 and 3-4 on waves 2-3
+    const int bhalf = (wave >> 1) & 1, bch0 = bhalf * 3, nbch = 3 - bhalf;
+    const float *colb = s_m + bch0 * FI_MC + ac;
     const int vi = (ac >> 1) + (ac & 1) * FI_HALF;
-    double *vo0 = s_v + (wave >> 1) * (FI_G * FI_MC) + vi;
-    double *vo1 = s_v + 4 * (FI_G * FI_MC) + vi;
-    const bool has1 = wave == 4 || wave == 5;
-    double v0 = 0.0, v1 = 0.0;
-    for (int i = 1; i <= 2 * FI_M; ++i) {                // first output row: rows ys-7 .. ys+6 = slots 1 .. 14
-        v0 += (double)col0[i * FI_MROW];
-        if (has1) v1 += (double)col1[i * FI_MROW];
+    double *vob = s_v + bch0 * (FI_G * FI_MC) + vi;
+    double vs[3] = {0.0, 0.0, 0.0};
+    if (!producer) {
+        for (int i = 1; i <= 2 * FI_M; ++i) {            // first output row: rows ys-7 .. ys+6 = slots 1 .. 14
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+                if (c < nbch) vs[c] += (double)colb[i * FI_MROW + c * FI_MC];
+        }
     }
     int slot_in = 15;                                    // slot of row yb+7 for yb = ys
     int slot_out = 1;                                    // slot of row ys-7, the first row to leave the window
     double msum = 0.0;
+    unsigned *s_flag = reinterpret_cast<unsigned *>(fi_lds + FI_LDS_BYTES - 16);   // B -> C hand-off counter of the consumers
+    if (tid == 0) *s_flag = 0;
+    unsigned flag_target = 0;
+    fi_barrier();
 
     auto phase_b = [&](bool first_step) {
 #pragma unroll
         for (int r = 0; r < FI_G; ++r) {
+            const float *pin = colb + slot_in * FI_MROW, *pout = colb + slot_out * FI_MROW;
             if (first_step && r == 0) {
-                v0 += (double)col0[slot_in * FI_MROW];
-                if (has1) v1 += (double)col1[slot_in * FI_MROW];
+#pragma unroll
+                for (int c = 0; c < 3; ++c)
+                    if (c < nbch) vs[c] += (double)pin[c * FI_MC];
             } else {
-                v0 += (double)col0[slot_in * FI_MROW] - (double)col0[slot_out * FI_MROW];
-                if (has1) v1 += (double)col1[slot_in * FI_MROW] - (double)col1[slot_out * FI_MROW];
+#pragma unroll
+                for (int c = 0; c < 3; ++c)
+                    if (c < nbch) vs[c] += (double)pin[c * FI_MC] - (double)pout[c * FI_MC];
                 slot_out = slot_out + 1 == FI_RING ? 0 : slot_out + 1;
             }
             slot_in = slot_in + 1 == FI_RING ? 0 : slot_in + 1;
-            vo0[r * FI_MC] = v0;
-            if (has1) vo1[r * FI_MC] = v1;
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+                if (c < nbch) vob[c * (FI_G * FI_MC) + r * FI_MC] = vs[c];
         }
     };
+    // the four consumer waves meet here between B and C; the producers are not held up by it
+    auto consumers_sync = [&]() {
+        flag_target += 4;
+        if ((tid & 63) == 0) __hip_atomic_fetch_add(s_flag, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        while (__hip_atomic_load(s_flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < flag_target) __builtin_amdgcn_s_sleep(1);
+    };
 
+#ifdef IPX_FI_STAMPS
+    unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_t = __builtin_amdgcn_s_memtime();
+#endif
     if (producer) {
 #pragma unroll 1
         for (int yb = ys; yb < ye; yb += FI_G) {
@@ -617,8 +667,7 @@ __global__ __launch_bounds__(FI_THREADS, 4) void flow_iter_kernel(const FiArgs a
                 const float2 d0 = vec_finish(dv0), d1 = vec_finish(dv1);
                 um_load(rR, P4, d0, ax, clamp_row(j0), h, w, in0);
                 um_load(rR, P4, d1, ax, clamp_row(j1), h, w, in1);
-                phase_b(yb == ys);
-                fi_barrier();
+                FI_STAMP(0);
                 float m[5];
                 um_finish(in0, d0, ax, clamp_row(j0), h, w, m);
                 ring_store(j0, m);
@@ -626,17 +675,18 @@ __global__ __launch_bounds__(FI_THREADS, 4) void flow_iter_kernel(const FiArgs a
                 ring_store(j1, m);
                 dv0 = vec_issue(clamp_row(j0 + FI_G));
                 dv1 = vec_issue(clamp_row(j1 + FI_G));
-            } else {
-                phase_b(yb == ys);
-                fi_barrier();
+                FI_STAMP(3);
             }
             fi_barrier();                                // ring rows of the next step written
+            FI_STAMP(4);
         }
     } else {
 #pragma unroll 1
         for (int yb = ys; yb < ye; yb += FI_G) {
             phase_b(yb == ys);
-            fi_barrier();
+            FI_STAMP(1);
+            consumers_sync();
+            FI_STAMP(2);
             // ---- C: horizontal sums + solve, row r = wave, outputs 2l, 2l+1 (l < 57)
             const int r = wave, l = tid & 63;
             const int y = yb + r;
@@ -683,9 +733,17 @@ __global__ __launch_bounds__(FI_THREADS, 4) void flow_iter_kernel(const FiArgs a
                     }
                 }
             }
+            FI_STAMP(3);
             fi_barrier();                                // s_v free again
+            FI_STAMP(4);
         }
     }
+#ifdef IPX_FI_STAMPS
+    if ((tid & 63) == 0 && (blockIdx.x & 63) == 0 && h > 600) {
+        for (int i = 0; i < 8; ++i) atomicAdd(&fi_stamps[wave][i], st_acc[i]);
+        atomicAdd(&fi_stamps[wave][7], (unsigned long long)((ye - ys + FI_G - 1) / FI_G));
+    }
+#endif
     if (REDUCE) {                                        // fixed-order sum of the workgroup's magnitudes
         for (int off = 32; off > 0; off >>= 1) msum += __shfl_down(msum, off);
         if ((tid & 63) == 0) s_v[wave] = msum;
@@ -974,6 +1032,18 @@ extern "C" int ipx_flow_metric(ipx_ctx *ctx, const uint8_t *frames, int n, int H
     }
     return IPX_OK;
 }
+
+#ifdef IPX_FI_STAMPS
+extern "C" __attribute__((visibility("default"))) int ipx_debug_fi_stamps(unsigned long long *out64, int reset)
+{
+    if (hipMemcpyFromSymbol(out64, HIP_SYMBOL(fi_stamps), sizeof(unsigned long long) * 64) != hipSuccess) return -1;
+    if (reset) {
+        unsigned long long z[64] = {0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(fi_stamps), z, sizeof(z)) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#endif
 
 namespace {
 __global__ void f32_to_u8_kernel(const float *src, size_t n, uint8_t *dst, int *bad)
