@@ -298,56 +298,79 @@ __global__ __launch_bounds__(256) void pyr_level_kernel(PyrArgs a)
     }
 }
 
-// FarnebackPolyExp: I [nf][h][w] -> R [nf][5][h][w].  Block = 64 columns x 4 rows; the vertical
-// pass (f32) of 64+10 columns is staged in LDS, the horizontal pass accumulates in f64.
-constexpr int PX_TW = 64, PX_TH = 4;
-__global__ __launch_bounds__(256) void polyexp_kernel(const float *I, int h, int w, PolyConst pc, float *R)
+// FarnebackPolyExp: I [nf][h][w] -> R [nf][5][h][w].  Workgroup = 64 columns x 16 rows:
+//   1. the (16+10) x (64+10) window of I (rows and columns clamped: the reference replicates them) goes to LDS,
+//   2. the vertical pass (f32, taps paired from the centre outwards) of the 74 columns goes to LDS,
+//   3. the horizontal pass accumulates in f64.  b1 and b4 are sums of products of two f32 values held in
+//      f64: the products are exact, so the fused multiply-add rounds exactly like the reference's mul + add.
+// Tiles are numbered frame-major and dealt to the 8 XCDs in contiguous ranges, so that vertically adjacent
+// tiles (which share 10 of 26 window rows) run on the same L2.
+constexpr int PX_TW = 64, PX_TH = 16, PX_SW = PX_TW + 2 * POLY_N, PX_SH = PX_TH + 2 * POLY_N, PX_SP = PX_SW + 1;
+__global__ __launch_bounds__(256) void polyexp_kernel(const float *I, int h, int w, int tiles_x, int tiles_y, int nf, PolyConst pc, float *R)
 {
-    __shared__ float s_row[PX_TH][3][PX_TW + 2 * POLY_N + 2];
-    const int lane = threadIdx.x & 63, ry = threadIdx.x >> 6;
-    const int x0 = blockIdx.x * PX_TW;
-    const int y = blockIdx.y * PX_TH + ry;
-    const size_t f = blockIdx.z;
-    const float *img = I + f * (size_t)h * w;
-    if (y < h) {
-        for (int c = lane; c < PX_TW + 2 * POLY_N; c += 64) {
-            int x = x0 - POLY_N + c;
-            x = x < 0 ? 0 : (x > w - 1 ? w - 1 : x);          // replicated vertical-pass columns
-            float t0 = img[(size_t)y * w + x] * pc.g[0], t1 = 0.f, t2 = 0.f;
-#pragma unroll
-            for (int k = 1; k <= POLY_N; ++k) {
-                const float s0 = img[(size_t)(y - k < 0 ? 0 : y - k) * w + x];
-                const float s1 = img[(size_t)(y + k > h - 1 ? h - 1 : y + k) * w + x];
-                const float p = s0 + s1;
-                t0 = t0 + pc.g[k] * p;
-                t1 = t1 + pc.xg[k] * (s1 - s0);
-                t2 = t2 + pc.xxg[k] * p;
-            }
-            s_row[ry][0][c] = t0; s_row[ry][1][c] = t1; s_row[ry][2][c] = t2;
-        }
+    __shared__ float s_in[PX_SH * PX_SP];
+    __shared__ float s_t[3][PX_TH][PX_SP];
+    const int tid = threadIdx.x;
+    const int per_frame = tiles_x * tiles_y, total = per_frame * nf, per_xcd = (total + 7) >> 3;
+    const int k = (int)(blockIdx.x >> 3);
+    const int tile = (int)(blockIdx.x & 7) * per_xcd + k;
+    if (k >= per_xcd || tile >= total) return;
+    const int f = tile / per_frame, rem = tile - f * per_frame;
+    const int ty = rem / tiles_x, tx = rem - ty * tiles_x;
+    const int x0 = tx * PX_TW, y0 = ty * PX_TH;
+    const float *img = I + (size_t)f * h * w;
+    // 1. window
+    for (int i = tid; i < PX_SH * PX_SW; i += 256) {
+        const int r = i / PX_SW, c = i - r * PX_SW;
+        int y = y0 - POLY_N + r, x = x0 - POLY_N + c;
+        y = y < 0 ? 0 : (y > h - 1 ? h - 1 : y);
+        x = x < 0 ? 0 : (x > w - 1 ? w - 1 : x);
+        s_in[r * PX_SP + c] = img[(size_t)y * w + x];
     }
     __syncthreads();
-    const int x = x0 + lane;
-    if (y >= h || x >= w) return;
-    const float *r0 = s_row[ry][0] + lane + POLY_N, *r1 = s_row[ry][1] + lane + POLY_N, *r2 = s_row[ry][2] + lane + POLY_N;
-    double b1 = r0[0] * pc.g[0], b2 = 0, b3 = r1[0] * pc.g[0], b4 = 0, b5 = r2[0] * pc.g[0], b6 = 0;
+    // 2. vertical pass
+    for (int i = tid; i < PX_TH * PX_SW; i += 256) {
+        const int r = i / PX_SW, c = i - r * PX_SW;
+        const float *S = s_in + (r + POLY_N) * PX_SP + c;
+        float t0 = S[0] * pc.g[0], t1 = 0.f, t2 = 0.f;
 #pragma unroll
-    for (int k = 1; k <= POLY_N; ++k) {
-        const double tg = r0[k] + r0[-k];
-        const float g0 = pc.g[k];
-        b1 += tg * g0; b4 += tg * pc.xxg[k];
-        b2 += (r0[k] - r0[-k]) * pc.xg[k];
-        b3 += (r1[k] + r1[-k]) * g0;
-        b6 += (r1[k] - r1[-k]) * pc.xg[k];
-        b5 += (r2[k] + r2[-k]) * g0;
+        for (int j = 1; j <= POLY_N; ++j) {
+            const float s0 = S[-j * PX_SP], s1 = S[j * PX_SP];
+            const float p = s0 + s1;
+            t0 = t0 + pc.g[j] * p;
+            t1 = t1 + pc.xg[j] * (s1 - s0);
+            t2 = t2 + pc.xxg[j] * p;
+        }
+        s_t[0][r][c] = t0; s_t[1][r][c] = t1; s_t[2][r][c] = t2;
     }
+    __syncthreads();
+    // 3. horizontal pass: lane = column, wave w takes rows w, w+4, ...
+    const int lane = tid & 63, x = x0 + lane;
+    if (x >= w) return;
     const size_t P = (size_t)h * w;
-    float *o = R + f * 5 * P + (size_t)y * w + x;
-    o[0] = (float)(b3 * pc.ig11);
-    o[P] = (float)(b2 * pc.ig11);
-    o[2 * P] = (float)(b1 * pc.ig03 + b5 * pc.ig33);
-    o[3 * P] = (float)(b1 * pc.ig03 + b4 * pc.ig33);
-    o[4 * P] = (float)(b6 * pc.ig55);
+    for (int r = tid >> 6; r < PX_TH; r += 4) {
+        const int y = y0 + r;
+        if (y >= h) break;
+        const float *r0 = s_t[0][r] + lane + POLY_N, *r1 = s_t[1][r] + lane + POLY_N, *r2 = s_t[2][r] + lane + POLY_N;
+        double b1 = r0[0] * pc.g[0], b2 = 0, b3 = r1[0] * pc.g[0], b4 = 0, b5 = r2[0] * pc.g[0], b6 = 0;
+#pragma unroll
+        for (int j = 1; j <= POLY_N; ++j) {
+            const double tg = r0[j] + r0[-j];
+            const float g0 = pc.g[j];
+            b1 = __builtin_fma(tg, (double)g0, b1);
+            b4 = __builtin_fma(tg, (double)pc.xxg[j], b4);
+            b2 += (r0[j] - r0[-j]) * pc.xg[j];
+            b3 += (r1[j] + r1[-j]) * g0;
+            b6 += (r1[j] - r1[-j]) * pc.xg[j];
+            b5 += (r2[j] + r2[-j]) * g0;
+        }
+        float *o = R + (size_t)f * 5 * P + (size_t)y * w + x;
+        o[0] = (float)(b3 * pc.ig11);
+        o[P] = (float)(b2 * pc.ig11);
+        o[2 * P] = (float)(b1 * pc.ig03 + b5 * pc.ig33);
+        o[3 * P] = (float)(b1 * pc.ig03 + b4 * pc.ig33);
+        o[4 * P] = (float)(b6 * pc.ig55);
+    }
 }
 
 // FarnebackUpdateMatrices at one pixel: the five entries (G11, G12, G22, h1, h2) from the
@@ -378,11 +401,12 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t ipx_make_rsrc(const void *base
 // rR: the pair's expansions, R0 planes 0..4 then R1 planes 5..9, P4 = bytes per plane.  The loads are
 // unconditional (no divergent control flow between issue and use): a sample position outside the image gets
 // an offset beyond the resource, for which the buffer load returns 0 without touching memory.
-__device__ __forceinline__ void um_load(__amdgpu_buffer_rsrc_t rR, unsigned P4, float2 d, int x, int y, int h, int w, UmIn &in)
+__device__ __forceinline__ void um_load(__amdgpu_buffer_rsrc_t rR, unsigned P4, float2 d, int x, int y, int h, int w, UmIn &in,
+                                        bool live = true)
 {
-    const unsigned o4 = (unsigned)(y * w + x) * 4u;
+    const unsigned o4 = live ? (unsigned)(y * w + x) * 4u : 0xfffffff0u;   // !live: nothing is fetched
     int x1, y1; float fx, fy;
-    const bool inb = um_position(d, x, y, h, w, x1, y1, fx, fy);
+    const bool inb = um_position(d, x, y, h, w, x1, y1, fx, fy) && live;
 #pragma unroll
     for (int c = 0; c < 5; ++c) in.r0[c] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rR, o4, c * P4, 0));
     const unsigned q0 = inb ? (unsigned)(y1 * w + x1) * 4u : 0xfffffff0u;
@@ -658,25 +682,39 @@ __global__ __launch_bounds__(FI_THREADS, 4) void flow_iter_kernel(const FiArgs a
     unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_t = __builtin_amdgcn_s_memtime();
 #endif
     if (producer) {
+        // Software pipeline over matrix rows: while one of the thread's two rows is finished and stored, the
+        // loads of the other (and of the row that replaces the finished one) are in flight, so the CU's
+        // memory pipe always has this wave's requests queued.
+        UmIn in0, in1;
+        float2 d0 = vec_finish(dv0), d1 = vec_finish(dv1);
+        {
+            const int j0 = ys + FI_M + FI_G + prow, j1 = j0 + 2;     // rows of step 1
+            const bool more = ys + FI_G < ye;
+            um_load(rR, P4, d0, ax, clamp_row(j0), h, w, in0, more);
+            um_load(rR, P4, d1, ax, clamp_row(j1), h, w, in1, more);
+            dv0 = vec_issue(clamp_row(j0 + FI_G));
+            dv1 = vec_issue(clamp_row(j1 + FI_G));
+        }
 #pragma unroll 1
         for (int yb = ys; yb < ye; yb += FI_G) {
-            const bool more = yb + FI_G < ye;            // the next step needs matrix rows yb+11 .. yb+14
+            const bool more = yb + FI_G < ye;            // the next step needs matrix rows yb+11 .. yb+14 (in flight)
+            const bool more2 = yb + 2 * FI_G < ye;       // and the one after it rows yb+15 .. yb+18 (issued here)
             const int j0 = yb + FI_M + FI_G + prow, j1 = j0 + 2;
-            if (more) {
-                UmIn in0, in1;
-                const float2 d0 = vec_finish(dv0), d1 = vec_finish(dv1);
-                um_load(rR, P4, d0, ax, clamp_row(j0), h, w, in0);
-                um_load(rR, P4, d1, ax, clamp_row(j1), h, w, in1);
-                FI_STAMP(0);
-                float m[5];
-                um_finish(in0, d0, ax, clamp_row(j0), h, w, m);
-                ring_store(j0, m);
-                um_finish(in1, d1, ax, clamp_row(j1), h, w, m);
-                ring_store(j1, m);
-                dv0 = vec_issue(clamp_row(j0 + FI_G));
-                dv1 = vec_issue(clamp_row(j1 + FI_G));
-                FI_STAMP(3);
-            }
+            float m[5];
+            um_finish(in0, d0, ax, clamp_row(j0), h, w, m);
+            if (more) ring_store(j0, m);
+            FI_STAMP(0);
+            d0 = vec_finish(dv0);
+            um_load(rR, P4, d0, ax, clamp_row(j0 + FI_G), h, w, in0, more2);
+            dv0 = vec_issue(clamp_row(j0 + 2 * FI_G));
+            FI_STAMP(1);
+            um_finish(in1, d1, ax, clamp_row(j1), h, w, m);
+            if (more) ring_store(j1, m);
+            FI_STAMP(2);
+            d1 = vec_finish(dv1);
+            um_load(rR, P4, d1, ax, clamp_row(j1 + FI_G), h, w, in1, more2);
+            dv1 = vec_issue(clamp_row(j1 + 2 * FI_G));
+            FI_STAMP(3);
             fi_barrier();                                // ring rows of the next step written
             FI_STAMP(4);
         }
@@ -830,7 +868,7 @@ int build_plan(ipx_ctx *ctx, int H, int W)
         }
         offs[k][8] = push(xs2.data(), xs2.size() * 4); offs[k][9] = push(ys2.data(), ys2.size() * 4);
         // tile: as many level rows as keep the staged source window within 64 rows (one lane per row in
-        // the row pass), as many level columns as keep the staged window within ~36 KB of LDS
+        // the row pass), as many level columns as keep the tile within 26 KB of LDS
         const int Rk = g.ksize / 2;
         auto extent = [&](const std::vector<int> &t2, int n, int tile) {
             int mx = 0;
@@ -842,6 +880,7 @@ int build_plan(ipx_ctx *ctx, int H, int W)
             return mx;
         };
         int toy = 1;
+        const size_t max_lds = 26 * 1024;                   // six workgroups per CU (measured: 52 KB tiles were 16 % slower)
         while (toy < g.lh && toy < 64 && extent(ys2, g.lh, toy + 1) <= 64) ++toy;
         g.toy = toy;
         g.src_rows = extent(ys2, g.lh, toy);
@@ -851,7 +890,7 @@ int build_plan(ipx_ctx *ctx, int H, int W)
             return ((size_t)g.src_rows * (sp + tp) + 2 * tx) * 4 + 16;
         };
         int tox = 64;
-        while (tox > 8 && lds_for(tox) > 52 * 1024) tox >>= 1;
+        while (tox > 8 && lds_for(tox) > max_lds) tox >>= 1;
         g.tox = tox;
         g.src_cols = extent(xs2, g.lw, tox);
         g.src_pitch = (g.src_cols + 7) | 1;
@@ -915,7 +954,8 @@ int launch_level_expansion(ipx_ctx *ctx, const LevelGeom &g, const uint8_t *fram
         return IPX_ERR_UNSUPPORTED;
     }
     if (ctx->prof.on) ipx_prof_end(ctx);
-    IPX_LAUNCH(ctx, KID_POLYEXP, 24.0 * nf * g.lh * g.lw, polyexp_kernel, dim3((g.lw + PX_TW - 1) / PX_TW, (g.lh + PX_TH - 1) / PX_TH, nf), block, I, g.lh, g.lw, pl->pc, R);
+    const int ptx = (g.lw + PX_TW - 1) / PX_TW, pty = (g.lh + PX_TH - 1) / PX_TH;
+    IPX_LAUNCH(ctx, KID_POLYEXP, 24.0 * nf * g.lh * g.lw, polyexp_kernel, dim3(8 * ((ptx * pty * nf + 7) / 8)), block, I, g.lh, g.lw, ptx, pty, nf, pl->pc, R);
     IPX_LAUNCH_CHECK();
     return IPX_OK;
 }
