@@ -298,13 +298,16 @@ __global__ __launch_bounds__(256) void pyr_level_kernel(PyrArgs a)
     }
 }
 
-// FarnebackPolyExp: I [nf][h][w] -> R [nf][5][h][w].  Workgroup = 64 columns x 16 rows:
+// FarnebackPolyExp: I [nf][h][w] -> R [nf][{float4 [h][w], float [h][w]}].  Workgroup = 64 columns x 16 rows:
 //   1. the (16+10) x (64+10) window of I (rows and columns clamped: the reference replicates them) goes to LDS,
 //   2. the vertical pass (f32, taps paired from the centre outwards) of the 74 columns goes to LDS,
 //   3. the horizontal pass accumulates in f64.  b1 and b4 are sums of products of two f32 values held in
 //      f64: the products are exact, so the fused multiply-add rounds exactly like the reference's mul + add.
 // Tiles are numbered frame-major and dealt to the 8 XCDs in contiguous ranges, so that vertically adjacent
 // tiles (which share 10 of 26 window rows) run on the same L2.
+// floats per frame of an expansion: 5 per pixel, rounded up so that every frame's float4 plane is 16-byte aligned
+__host__ __device__ inline size_t r_stride(size_t P) { return (5 * P + 3) & ~(size_t)3; }
+
 constexpr int PX_TW = 64, PX_TH = 16, PX_SW = PX_TW + 2 * POLY_N, PX_SH = PX_TH + 2 * POLY_N, PX_SP = PX_SW + 1;
 __global__ __launch_bounds__(256) void polyexp_kernel(const float *I, int h, int w, int tiles_x, int tiles_y, int nf, PolyConst pc, float *R)
 {
@@ -364,12 +367,12 @@ __global__ __launch_bounds__(256) void polyexp_kernel(const float *I, int h, int
             b6 += (r1[j] - r1[-j]) * pc.xg[j];
             b5 += (r2[j] + r2[-j]) * g0;
         }
-        float *o = R + (size_t)f * 5 * P + (size_t)y * w + x;
-        o[0] = (float)(b3 * pc.ig11);
-        o[P] = (float)(b2 * pc.ig11);
-        o[2 * P] = (float)(b1 * pc.ig03 + b5 * pc.ig33);
-        o[3 * P] = (float)(b1 * pc.ig03 + b4 * pc.ig33);
-        o[4 * P] = (float)(b6 * pc.ig55);
+        // expansion of a frame: a float4 plane (coefficients 0-3) followed by a float plane (coefficient 4)
+        float *fr = R + (size_t)f * r_stride(P);
+        const size_t o = (size_t)y * w + x;
+        *reinterpret_cast<float4 *>(fr + 4 * o) = make_float4((float)(b3 * pc.ig11), (float)(b2 * pc.ig11),
+                                                             (float)(b1 * pc.ig03 + b5 * pc.ig33), (float)(b1 * pc.ig03 + b4 * pc.ig33));
+        fr[4 * P + o] = (float)(b6 * pc.ig55);
     }
 }
 
@@ -398,49 +401,35 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t ipx_make_rsrc(const void *base
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, (int)bytes, 0x00020000);
 }
 
-// rR: the pair's expansions, R0 planes 0..4 then R1 planes 5..9, P4 = bytes per plane.  The loads are
+// rR: the expansions of the pair's two frames (layout: polyexp_kernel), FS = bytes per frame, P16 = byte
+// offset of the fifth coefficient's plane.  16-byte loads fetch coefficients 0-3 of one pixel; the loads are
 // unconditional (no divergent control flow between issue and use): a sample position outside the image gets
 // an offset beyond the resource, for which the buffer load returns 0 without touching memory.
-__device__ __forceinline__ void um_load(__amdgpu_buffer_rsrc_t rR, unsigned P4, float2 d, int x, int y, int h, int w, UmIn &in,
-                                        bool live = true)
+typedef unsigned int ipx_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void um_load(__amdgpu_buffer_rsrc_t rR, unsigned FS, unsigned P16, float2 d, int x, int y, int h, int w,
+                                        UmIn &in, bool live = true)
 {
-    const unsigned o4 = live ? (unsigned)(y * w + x) * 4u : 0xfffffff0u;   // !live: nothing is fetched
+    const unsigned o1 = (unsigned)(y * w + x);
+    const unsigned dead = 0xfffffff0u;
     int x1, y1; float fx, fy;
     const bool inb = um_position(d, x, y, h, w, x1, y1, fx, fy) && live;
-#pragma unroll
-    for (int c = 0; c < 5; ++c) in.r0[c] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rR, o4, c * P4, 0));
-    const unsigned q0 = inb ? (unsigned)(y1 * w + x1) * 4u : 0xfffffff0u;
-    const unsigned q1 = inb ? q0 + (unsigned)w * 4u : 0xfffffff0u;
-#if defined(FI_EXP) && FI_EXP == 1
-#pragma unroll
-    for (int c = 0; c < 5; ++c) {
-        const unsigned a_ = __builtin_amdgcn_raw_buffer_load_b32(rR, q0, (5 + c) * P4, 0);
-        const unsigned b_ = __builtin_amdgcn_raw_buffer_load_b32(rR, q1, (5 + c) * P4, 0);
-        in.q[c][0] = __uint_as_float(a_); in.q[c][1] = __uint_as_float(a_);
-        in.q[c][2] = __uint_as_float(b_); in.q[c][3] = __uint_as_float(b_);
-    }
-    return;
-#elif defined(FI_EXP) && FI_EXP == 2
-#pragma unroll
-    for (int c = 0; c < 5; ++c) {
-        const ipx_u32x2 a = __builtin_amdgcn_raw_buffer_load_b64(rR, o4, (c) * P4, 0);
-        const ipx_u32x2 b = __builtin_amdgcn_raw_buffer_load_b64(rR, o4, (c) * P4, 0);
-        in.q[c][0] = __uint_as_float(a.x) + q0; in.q[c][1] = __uint_as_float(a.y);
-        in.q[c][2] = __uint_as_float(b.x) + q1; in.q[c][3] = __uint_as_float(b.y);
-    }
-    return;
-#elif defined(FI_EXP) && FI_EXP == 3
-#pragma unroll
-    for (int c = 0; c < 5; ++c) { in.q[c][0] = q0; in.q[c][1] = q1; in.q[c][2] = q0; in.q[c][3] = q1; }
-    return;
-#endif
-#pragma unroll
-    for (int c = 0; c < 5; ++c) {
-        const ipx_u32x2 a = __builtin_amdgcn_raw_buffer_load_b64(rR, q0, (5 + c) * P4, 0);
-        const ipx_u32x2 b = __builtin_amdgcn_raw_buffer_load_b64(rR, q1, (5 + c) * P4, 0);
-        in.q[c][0] = __uint_as_float(a.x); in.q[c][1] = __uint_as_float(a.y);
-        in.q[c][2] = __uint_as_float(b.x); in.q[c][3] = __uint_as_float(b.y);
-    }
+    const ipx_u32x4 c03 = __builtin_amdgcn_raw_buffer_load_b128(rR, live ? o1 * 16u : dead, 0, 0);
+    in.r0[4] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rR, live ? o1 * 4u : dead, P16, 0));
+    in.r0[0] = __uint_as_float(c03.x); in.r0[1] = __uint_as_float(c03.y);
+    in.r0[2] = __uint_as_float(c03.z); in.r0[3] = __uint_as_float(c03.w);
+    const unsigned q1 = (unsigned)(y1 * w + x1);
+    const unsigned qa = inb ? q1 * 16u : dead, qb = inb ? (q1 + (unsigned)w) * 16u : dead;
+    const ipx_u32x4 s00 = __builtin_amdgcn_raw_buffer_load_b128(rR, qa, FS, 0);
+    const ipx_u32x4 s01 = __builtin_amdgcn_raw_buffer_load_b128(rR, inb ? qa + 16u : dead, FS, 0);
+    const ipx_u32x4 s10 = __builtin_amdgcn_raw_buffer_load_b128(rR, qb, FS, 0);
+    const ipx_u32x4 s11 = __builtin_amdgcn_raw_buffer_load_b128(rR, inb ? qb + 16u : dead, FS, 0);
+    const ipx_u32x2 e0 = __builtin_amdgcn_raw_buffer_load_b64(rR, inb ? q1 * 4u : dead, FS + P16, 0);
+    const ipx_u32x2 e1 = __builtin_amdgcn_raw_buffer_load_b64(rR, inb ? (q1 + (unsigned)w) * 4u : dead, FS + P16, 0);
+    in.q[0][0] = __uint_as_float(s00.x); in.q[0][1] = __uint_as_float(s01.x); in.q[0][2] = __uint_as_float(s10.x); in.q[0][3] = __uint_as_float(s11.x);
+    in.q[1][0] = __uint_as_float(s00.y); in.q[1][1] = __uint_as_float(s01.y); in.q[1][2] = __uint_as_float(s10.y); in.q[1][3] = __uint_as_float(s11.y);
+    in.q[2][0] = __uint_as_float(s00.z); in.q[2][1] = __uint_as_float(s01.z); in.q[2][2] = __uint_as_float(s10.z); in.q[2][3] = __uint_as_float(s11.z);
+    in.q[3][0] = __uint_as_float(s00.w); in.q[3][1] = __uint_as_float(s01.w); in.q[3][2] = __uint_as_float(s10.w); in.q[3][3] = __uint_as_float(s11.w);
+    in.q[4][0] = __uint_as_float(e0.x); in.q[4][1] = __uint_as_float(e0.y); in.q[4][2] = __uint_as_float(e1.x); in.q[4][3] = __uint_as_float(e1.y);
 }
 
 __device__ __forceinline__ void um_finish(const UmIn &in, float2 d, int x, int y, int h, int w, float (&m)[5])
@@ -562,8 +551,8 @@ __global__ __launch_bounds__(FI_THREADS, 4) void flow_iter_kernel(const FiArgs a
     if (ys >= h || p >= (size_t)np) return;
     const int ye = min(h, ys + seg_rows);
     const size_t P = (size_t)h * w;
-    const __amdgpu_buffer_rsrc_t rR = ipx_make_rsrc(R + p * 5 * P, (unsigned)(10 * P * 4));
-    const unsigned P4 = (unsigned)(P * 4);
+    const unsigned FS = (unsigned)(r_stride(P) * 4), P16 = (unsigned)(P * 16);
+    const __amdgpu_buffer_rsrc_t rR = ipx_make_rsrc(R + p * r_stride(P), 2 * FS);
     const float2 *fin = a.flow_in + p * (IN == 2 ? (size_t)a.sh * a.sw : P);
     float2 *fout = a.flow_out + p * P;
 
@@ -617,7 +606,7 @@ __global__ __launch_bounds__(FI_THREADS, 4) void flow_iter_kernel(const FiArgs a
         const float2 d = vec_finish(vec_issue(y));
         UmIn in;
         float m[5];
-        um_load(rR, P4, d, ax, y, h, w, in);
+        um_load(rR, FS, P16, d, ax, y, h, w, in);
         um_finish(in, d, ax, y, h, w, m);
         ring_store(j, m);
     }
@@ -690,8 +679,8 @@ __global__ __launch_bounds__(FI_THREADS, 4) void flow_iter_kernel(const FiArgs a
         {
             const int j0 = ys + FI_M + FI_G + prow, j1 = j0 + 2;     // rows of step 1
             const bool more = ys + FI_G < ye;
-            um_load(rR, P4, d0, ax, clamp_row(j0), h, w, in0, more);
-            um_load(rR, P4, d1, ax, clamp_row(j1), h, w, in1, more);
+            um_load(rR, FS, P16, d0, ax, clamp_row(j0), h, w, in0, more);
+            um_load(rR, FS, P16, d1, ax, clamp_row(j1), h, w, in1, more);
             dv0 = vec_issue(clamp_row(j0 + FI_G));
             dv1 = vec_issue(clamp_row(j1 + FI_G));
         }
@@ -705,14 +694,14 @@ __global__ __launch_bounds__(FI_THREADS, 4) void flow_iter_kernel(const FiArgs a
             if (more) ring_store(j0, m);
             FI_STAMP(0);
             d0 = vec_finish(dv0);
-            um_load(rR, P4, d0, ax, clamp_row(j0 + FI_G), h, w, in0, more2);
+            um_load(rR, FS, P16, d0, ax, clamp_row(j0 + FI_G), h, w, in0, more2);
             dv0 = vec_issue(clamp_row(j0 + 2 * FI_G));
             FI_STAMP(1);
             um_finish(in1, d1, ax, clamp_row(j1), h, w, m);
             if (more) ring_store(j1, m);
             FI_STAMP(2);
             d1 = vec_finish(dv1);
-            um_load(rR, P4, d1, ax, clamp_row(j1 + FI_G), h, w, in1, more2);
+            um_load(rR, FS, P16, d1, ax, clamp_row(j1 + FI_G), h, w, in1, more2);
             dv1 = vec_issue(clamp_row(j1 + 2 * FI_G));
             FI_STAMP(3);
             fi_barrier();                                // ring rows of the next step written
@@ -992,7 +981,7 @@ int run_pairs(ipx_ctx *ctx, const uint8_t *frames, const uint8_t *extra, int fir
     const int nf = np + 1;
     const size_t P0 = (size_t)pl->lv[0].lh * pl->lv[0].lw;
     void *pyr, *uv;
-    IPX_TRY(ipx_scratch(ctx, SLOT_FLOW_PYR, (size_t)nf * P0 * 6 * sizeof(float) + 512, &pyr));
+    IPX_TRY(ipx_scratch(ctx, SLOT_FLOW_PYR, ((size_t)nf * P0 + 64 + (size_t)nf * r_stride(P0)) * sizeof(float) + 512, &pyr));
     IPX_TRY(ipx_scratch(ctx, SLOT_FLOW_UV, 2 * (size_t)np * P0 * sizeof(float2) + 512, &uv));
     // two flow buffers, every iteration reads `cur` and writes `other`; the first iteration of a level
     // reads the coarser level's result (or nothing at the coarsest level)
