@@ -37,7 +37,7 @@ def parse():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--motion", action="store_true", help="camera-motion-heavy sequence (configs[3])")
-    ap.add_argument("--cpu-frames", type=int, default=8, help="frames of the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--cpu-frames", type=int, default=128, help="frames of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-profile", action="store_true", help="do not record per-kernel events (roofline = null)")
     return ap.parse_args()
 

@@ -483,12 +483,19 @@ __device__ __forceinline__ void um_finish(const UmIn &in, float2 d, int x, int y
 //      register (+ new row - row leaving the window), writing the 4 rows of sums to LDS;
 //   C  (waves 0-3, one row each) horizontal 15-sums slide over two adjacent outputs per thread, then the
 //      2x2 solve and the store (or the magnitude sum).
-// Two LDS-only barriers per step; the ring is large enough (rows yb-8 .. yb+14) that the producers never
-// write a row B still reads.  79,360 bytes of LDS: two workgroups per CU.
-// Only the horizontal halo (128/114) and 18 rows per segment are computed twice.
-// Measured on MI355X (PMC, 1080p): the unspecialised form of this kernel (every wave A, then B, then C)
-// kept the VALU 45 % and the LDS 46 % busy with the waves parked 64 % of the time; it was NOT limited
-// by HBM or fabric traffic (halving the fetched bytes left its time unchanged).
+// One workgroup barrier per step (plus an LDS counter on which the four consumer waves meet between B and C);
+// the ring is large enough (rows yb-8 .. yb+14) that the producers never write a row B still reads.
+// 79,376 bytes of LDS: two workgroups per CU.  Only the horizontal halo (128/114) and 18 rows per segment
+// are computed twice.
+// Measured on MI355X (in-kernel stamps + PMC, 1080p, two workgroups per CU): a step takes ~5.5k cycles.  The
+// producers spend all of it blocked on the vector memory pipe (issue or data): the CU fetches ~25 KB of L1
+// misses per workgroup step, i.e. ~9 B/cycle/CU, which is what one CU gets from the fabric (~46 requests
+// outstanding at ~480 cycles each).  HBM itself is far from busy (halving the L2 misses with the XCD-aware
+// order changed nothing), and so are VALU (45 %) and LDS (46 %).  What moved the time: fewer L1 line requests
+// per pixel (float4 expansion planes: 8 loads instead of 15), keeping requests queued at all times (row
+// pipeline), taking B and the B->C hand-off off the producers.  What did not: replacing the barrier by
+// counters so that the producers run ahead (5.7k: the memory pipe, not the waiting, sets their pace), deeper
+// prefetch, 64-column strips, one output per thread in C.
 constexpr int FI_M = 7, FI_MC = 128, FI_G = 4, FI_TW = FI_MC - 2 * FI_M, FI_THREADS = 512;
 constexpr int FI_RING = 23, FI_MROW = 5 * FI_MC, FI_HALF = FI_MC / 2;
 constexpr size_t FI_LDS_BYTES = FI_RING * FI_MROW * sizeof(float) + 5 * FI_G * FI_MC * sizeof(double) + 16;   // + hand-off counter

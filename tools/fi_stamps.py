@@ -14,7 +14,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-EXP = os.environ.get("FI_EXP", "")
+EXP = ""
 LIBDIR = os.path.join(ROOT, "image_processing_amd", "lib_stamps" + EXP)
 LIB = os.path.join(LIBDIR, "libipx.so")
 
