@@ -495,7 +495,10 @@ __device__ __forceinline__ void um_finish(const UmIn &in, float2 d, int x, int y
 // per pixel (float4 expansion planes: 8 loads instead of 15), keeping requests queued at all times (row
 // pipeline), taking B and the B->C hand-off off the producers.  What did not: replacing the barrier by
 // counters so that the producers run ahead (5.7k: the memory pipe, not the waiting, sets their pace), deeper
-// prefetch, 64-column strips, one output per thread in C.
+// prefetch, 64-column strips, one output per thread in C, and 1024-thread workgroups whose two halves take
+// consecutive pairs in lockstep so that the shared expansion is fetched once per CU (the half that benefits
+// drops to 3.6k of producer work, but the coupled barrier costs more than that: 6.0k per step; with one
+// counter barrier per half the halves drift apart and the slower one sets the time).
 constexpr int FI_M = 7, FI_MC = 128, FI_G = 4, FI_TW = FI_MC - 2 * FI_M, FI_THREADS = 512;
 constexpr int FI_RING = 23, FI_MROW = 5 * FI_MC, FI_HALF = FI_MC / 2;
 constexpr size_t FI_LDS_BYTES = FI_RING * FI_MROW * sizeof(float) + 5 * FI_G * FI_MC * sizeof(double) + 16;   // + hand-off counter
