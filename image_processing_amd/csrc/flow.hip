@@ -177,6 +177,7 @@ struct PyrArgs {
     int first;                 // chunk index of launch frame 0 (may be -1 when `extra` is given)
     int H, W, lh, lw, mode;
     int tox, toy, src_pitch, tmp_pitch, src_rows;
+    int tiles_x, tiles_y, nf;
     const int *xs2; const float *x_a; const int *ys2; const float *y_b;
     float *out;                // [nf][lh][lw]
     KernTaps kt;
@@ -199,9 +200,16 @@ __global__ __launch_bounds__(256) void pyr_level_kernel(PyrArgs a)
     int *s_col = reinterpret_cast<int *>(s_tmp + a.src_rows * a.tmp_pitch);
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int ns = a.mode == 0 ? 1 : 2;
-    const int dx0 = blockIdx.x * a.tox, dy0 = blockIdx.y * a.toy;
+    // tiles are numbered frame-major and dealt to the 8 XCDs in contiguous ranges: neighbouring tiles, which
+    // share their source halo, run on the same L2
+    const int per_frame = a.tiles_x * a.tiles_y, total = per_frame * a.nf, per_xcd = (total + 7) >> 3;
+    const int tk = (int)(blockIdx.x >> 3), tile = (int)(blockIdx.x & 7) * per_xcd + tk;
+    if (tk >= per_xcd || tile >= total) return;
+    const int f = tile / per_frame, trem = tile - f * per_frame;
+    const int tby = trem / a.tiles_x, tbx = trem - tby * a.tiles_x;
+    const int dx0 = tbx * a.tox, dy0 = tby * a.toy;
     const int ndx = min(a.tox, a.lw - dx0), ndy = min(a.toy, a.lh - dy0);
-    const int f = blockIdx.z, fi = a.first + f;
+    const int fi = a.first + f;
     const uint8_t *frame = fi < 0 ? a.extra : a.frames + (size_t)fi * a.H * a.W;
     const int xlo = a.xs2[2 * dx0], xhi = a.xs2[2 * (dx0 + ndx - 1) + 1];
     const int ylo = a.ys2[2 * dy0], yhi = a.ys2[2 * (dy0 + ndy - 1) + 1];
@@ -941,7 +949,8 @@ int launch_level_expansion(ipx_ctx *ctx, const LevelGeom &g, const uint8_t *fram
     a.mode = g.mode; a.tox = g.tox; a.toy = g.toy; a.src_pitch = g.src_pitch; a.tmp_pitch = g.tmp_pitch;
     a.src_rows = g.src_rows; a.xs2 = g.xs2; a.x_a = g.x_a; a.ys2 = g.ys2; a.y_b = g.y_b; a.out = I;
     memcpy(a.kt.k, g.kern, sizeof(a.kt.k));
-    const dim3 grid((g.lw + g.tox - 1) / g.tox, (g.lh + g.toy - 1) / g.toy, nf), block(256);
+    a.tiles_x = (g.lw + g.tox - 1) / g.tox; a.tiles_y = (g.lh + g.toy - 1) / g.toy; a.nf = nf;
+    const dim3 grid(8 * ((a.tiles_x * a.tiles_y * nf + 7) / 8)), block(256);
     const double pyr_bytes = (double)nf * ((double)pl->H * pl->W + 4.0 * g.lh * g.lw);
     if (ctx->prof.on) ipx_prof_begin(ctx, KID_PYR, pyr_bytes);
     switch (g.ksize) {
@@ -965,7 +974,7 @@ FiGeom fi_geometry(const LevelGeom &g, int np)
 {
     FiGeom f;
     f.strips = (g.lw + FI_TW - 1) / FI_TW;
-    int nseg = (4096 + f.strips * np - 1) / (f.strips * np);
+    int nseg = (4096 + f.strips * np - 1) / (f.strips * np);   // measured flat between 1536 and 4096 workgroups
     const int max_seg = (g.lh + 63) / 64;
     if (nseg > max_seg) nseg = max_seg;
     if (nseg < 1) nseg = 1;
