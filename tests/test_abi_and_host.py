@@ -101,3 +101,28 @@ def test_pow2_table_is_python_pow():
     assert dim >= 48 and tab.shape == (dim * dim,)
     for a, d in [(0, 0), (3, 7), (10, 4), (20, 20)]:
         assert tab[a * dim + d] == (a * 1.0 + d * hostmath.SQRT2_F32) ** 2
+
+
+def test_no_64bit_shift_by_last_allocated_vgpr():
+    """gfx950 mis-executes a 64-bit vector shift whose amount is the last VGPR of the allocation (measured:
+    tools/hwtest/seg_loop.hip); the build refuses such kernels, and so does this test."""
+    import importlib.util
+    import os
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "check_shift64.py")
+    spec = importlib.util.spec_from_file_location("check_shift64", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    sample = """
+_Zbad:
+\tv_lshlrev_b64 v[12:13], v15, -1
+\ts_endpgm
+\t.amdhsa_kernel _Zbad
+\t\t.amdhsa_next_free_vgpr 16
+_Zgood:
+\tv_lshlrev_b64 v[12:13], v15, -1
+\ts_endpgm
+\t.amdhsa_kernel _Zgood
+\t\t.amdhsa_next_free_vgpr 17
+"""
+    assert [b[0] for b in mod.check_asm(sample)] == ["_Zbad"]
+    assert mod.check_library() == []

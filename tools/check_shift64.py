@@ -1,0 +1,91 @@
+#!/usr/bin/env python3
+"""Build-time guard against a gfx950 / hipcc 7.2 problem measured in round 1 (tools/hwtest/seg_loop.hip):
+
+a 64-bit vector shift whose shift-amount VGPR is the LAST register of the wave's allocation (the kernel's
+next_free_vgpr is a multiple of the allocation granule and the amount sits in next_free_vgpr - 1) sometimes
+shifts by the low bits of a register of the neighbouring allocation.  LLVM knows this as gfx90a's
+Shift64HighRegBug; hipcc 7.2 does not apply the workaround to gfx950.
+
+    python tools/check_shift64.py            compiles every csrc/*.hip to ISA and lists offending kernels (exit 1)
+
+A kernel is cured by allocating one more register: IPX_VGPR_PAD(n) (ipx_internal.h) with n = the kernel's
+next_free_vgpr printed here.
+"""
+import os
+import re
+import subprocess
+import sys
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GRANULE = 8
+
+
+def kernels_of(asm_text):
+    """yield (name, body_lines, next_free_vgpr)"""
+    cur, body, out = None, [], []
+    free = {}
+    for line in asm_text.splitlines():
+        m = re.match(r"^([A-Za-z_][\w$.]*):\s*(;.*)?$", line)
+        if m and not line.startswith(".L"):
+            if cur:
+                out.append((cur, body))
+            cur, body = m.group(1), []
+            continue
+        m = re.match(r"\s*\.amdhsa_kernel\s+(\S+)", line)
+        if m:
+            kname = m.group(1)
+            continue
+        m = re.match(r"\s*\.amdhsa_next_free_vgpr\s+(\d+)", line)
+        if m:
+            free[kname] = int(m.group(1))
+            continue
+        if cur:
+            body.append(line)
+    if cur:
+        out.append((cur, body))
+    for name, b in out:
+        if name in free:
+            yield name, b, free[name]
+
+
+SHIFT = re.compile(r"\s*(v_lshlrev_b64|v_lshrrev_b64|v_ashrrev_i64)\s+v\[\d+:\d+\],\s*v(\d+)\s*,")
+
+
+def check_asm(asm_text):
+    bad = []
+    for name, body, nfree in kernels_of(asm_text):
+        if nfree % GRANULE:
+            continue
+        for line in body:
+            m = SHIFT.match(line)
+            if m and int(m.group(2)) == nfree - 1:
+                bad.append((name, nfree, line.strip()))
+    return bad
+
+
+def compile_to_asm(src, flags):
+    with tempfile.TemporaryDirectory() as td:
+        out = os.path.join(td, "k.s")
+        subprocess.check_call(["/opt/rocm/bin/hipcc"] + flags + ["-S", "--cuda-device-only", "-o", out, src],
+                              stderr=subprocess.DEVNULL)
+        with open(out) as f:
+            return f.read()
+
+
+def check_library():
+    sys.path.insert(0, ROOT)
+    from image_processing_amd import build as b
+    flags = [f for f in b.FLAGS if f not in ("-fPIC",)]
+    bad = []
+    for s in b.SOURCES:
+        bad += [(s,) + x for x in check_asm(compile_to_asm(os.path.join(b.CSRC, s), flags))]
+    return bad
+
+
+if __name__ == "__main__":
+    bad = check_library()
+    for src, name, nfree, line in bad:
+        print("%s: kernel %s (next_free_vgpr %d): %s" % (src, name, nfree, line))
+    print("%d offending shift(s)" % len(bad))
+    sys.exit(1 if bad else 0)
