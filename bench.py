@@ -7,7 +7,7 @@ A step = one pass of the whole path (ipx_detect_chunk's stages, ip.py:526-632) o
 synthetic 1920x1080 uint8 frames already resident in HBM, results copied back and turned into the
 reference's four float64 arrays.  N = 1: BASELINE.json configs[1] ("1 MI355X, 1920x1080 synthetic
 video", processed in the reference's 1000-frame chunks).  N > 1 (launched by torch.distributed.run,
-one rank per GPU): configs[2], each chunk is sharded by frame range, --frames frames per GPU
+one rank per GPU): configs[2], a chunk of N x 1000 frames is sharded by frame range, 1000 frames per GPU
 (weak scaling), with the persistence / static-map / result exchanges over RCCL inside the step.
 
 Rank 0 prints ONE JSON line.  `roofline` is measured live: libipx's built-in profiler records HIP
@@ -33,7 +33,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--frames", type=int, default=None, help="frames per GPU per step (default 1000 at N=1, 256 at N>1)")
+    ap.add_argument("--frames", type=int, default=None, help="frames per GPU per step (default 1000)")
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--motion", action="store_true", help="camera-motion-heavy sequence (configs[3])")
@@ -85,15 +85,22 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # rehearsal of the N > 1 path on a one-GPU box: IPX_BENCH_REHEARSE=1 puts every rank on GPU 0 over gloo
+    rehearse = os.environ.get("IPX_BENCH_REHEARSE") == "1"
+    if rehearse:
+        local_rank = 0
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     assert world == args.gpus, "--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world)
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
     H, W = args.height, args.width
-    F = args.frames or (1000 if world == 1 else 256)
+    F = args.frames or 1000                  # the same work per GPU at every N (weak scaling)
     n_total = F * world
     eng = Engine(local_rank)
     comm = sharding.make_comm()
@@ -157,7 +164,7 @@ def main():
     if not args.no_profile:
         eng.profile_enable(False)
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device="cpu" if rehearse else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 

@@ -53,13 +53,26 @@ class _Dist:
         self.group = group
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
+        # RCCL ("nccl") moves device tensors directly; gloo (CPU rehearsals of the multi-rank path) is given
+        # host copies, because it has no device all_gather
+        self.stage = dist.get_backend(group) == "gloo"
 
     def all_gather(self, t):
+        if self.stage and t.is_cuda:
+            h = t.contiguous().cpu()
+            out = [torch.empty_like(h) for _ in range(self.world)]
+            self.dist.all_gather(out, h, group=self.group)
+            return [o.to(t.device) for o in out]
         out = [torch.empty_like(t) for _ in range(self.world)]
         self.dist.all_gather(out, t.contiguous(), group=self.group)
         return out
 
     def all_reduce_sum(self, t):
+        if self.stage and t.is_cuda:
+            h = t.cpu()
+            self.dist.all_reduce(h, op=self.dist.ReduceOp.SUM, group=self.group)
+            t.copy_(h)
+            return t
         self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
         return t
 
