@@ -35,17 +35,21 @@ except ImportError:                     # ip.py:26-33
 from image_processing_amd import avi as _avi
 from image_processing_amd import hostmath as _hostmath
 
-_ENGINE = None
+import threading as _threading
+
+_TLS = _threading.local()
 
 
 def _engine():
-    """The process-wide libipx context on the current torch device (created on first use)."""
-    global _ENGINE
-    if _ENGINE is None:
+    """This thread's libipx context on the current torch device (created on first use).  libipx wants one
+    context per (device, host thread); the reference calls its stages from worker threads (ip.py:342, 870)
+    and the chunk driver below decodes on a second thread."""
+    eng = getattr(_TLS, "engine", None)
+    if eng is None:
         import torch
         from image_processing_amd.engine import Engine
-        _ENGINE = Engine(torch.cuda.current_device() if torch.cuda.is_available() else 0)
-    return _ENGINE
+        eng = _TLS.engine = Engine(torch.cuda.current_device() if torch.cuda.is_available() else 0)
+    return eng
 
 
 class _Scoped:
@@ -669,6 +673,55 @@ def _video_info(video_filename):
     return n, fps
 
 
+def _load_chunk(video_filename, start, end):
+    """Decode frames [start, end) through the module's load_video_frames; when they are plain greyscale
+    uint8 frames of one size they are also stacked into pinned host memory for the asynchronous upload."""
+    frames = load_video_frames(video_filename, frames_start=start, frames_end=end)
+    pinned = None
+    try:
+        import torch
+        f0 = np.asarray(frames[0]) if len(frames) else None
+        if f0 is not None and f0.ndim == 2 and f0.dtype == np.uint8 and torch.cuda.is_available() and \
+                all(isinstance(f, np.ndarray) and f.shape == f0.shape and f.dtype == np.uint8 for f in frames):
+            pinned = torch.empty((len(frames),) + f0.shape, dtype=torch.uint8, pin_memory=True)
+            np.stack(frames, out=pinned.numpy())
+    except Exception:                                   # anything unusual: the synchronous path copes or raises
+        pinned = None
+    return frames, pinned
+
+
+def _submit_chunk(chunk, idx, kw):
+    """Start one chunk; returns a callable that yields detect_damaged_pixels' four arrays.  The asynchronous
+    path (pinned -> HBM on a side stream, ipx_detect_chunk enqueued, results copied back behind it) is taken
+    when nothing has to be plotted and no stage of this module has been replaced; otherwise the chunk goes
+    through the module-global detect_damaged_pixels right here."""
+    frames, pinned = chunk
+    n = len(frames)
+    if pinned is None or n < 2 or kw["plot"] or not _pristine(*_STAGES) or not _pristine("detect_damaged_pixels"):
+        res = detect_damaged_pixels(frames, idx, **kw)
+        return lambda: res
+    import torch
+    settings = _prepare_settings(kw["params"])
+    with _Scoped(**_engine_params(settings)) as eng:
+        copy_stream = getattr(_TLS, "copy_stream", None)
+        if copy_stream is None:
+            copy_stream = _TLS.copy_stream = torch.cuda.Stream(eng.device)
+        dev = torch.empty(pinned.shape, dtype=torch.uint8, device=eng.device)
+        with torch.cuda.stream(copy_stream):
+            dev.copy_(pinned, non_blocking=True)
+            uploaded = torch.cuda.Event()
+            uploaded.record(copy_stream)
+        torch.cuda.current_stream(eng.device).wait_event(uploaded)
+        handle = eng.detect_chunk_async(dev)
+
+    def finish():
+        r = handle.result()
+        del pinned_keepalive[:]
+        return r["total_counts"], r["cluster_counts"], r["avg_sizes"], r["avg_brightnesses"]
+    pinned_keepalive = [pinned, dev]
+    return finish
+
+
 def main(video_filename, average_time=1.0, max_chunks=None, step_size=1000, plot=False, show_plots=False,
          save_plots=False, output_folder="results", visualise_damaged_pixels_plot=True, plot_damaged_pixels_plot=True,
          plot_heatmap_plot=True, params=None):
@@ -682,17 +735,32 @@ def main(video_filename, average_time=1.0, max_chunks=None, step_size=1000, plot
         edges = edges[:max_chunks + 1]
     per_chunk = ([], [], [], [])
     step = int(round(FPS * average_time))
-    for idx in range(len(edges) - 1):
-        start, end = edges[idx], edges[idx + 1]
-        print(f"processing chunk {idx}: frames {start}–{end}")
-        chunk = load_video_frames(video_filename, frames_start=start, frames_end=end)
-        res = detect_damaged_pixels(chunk, idx, plot=plot, show_plots=show_plots, save_plots=save_plots,
-                                    output_folder=output_folder,
-                                    visualise_damaged_pixels_plot=visualise_damaged_pixels_plot,
-                                    plot_damaged_pixels_plot=plot_damaged_pixels_plot,
-                                    plot_heatmap_plot=plot_heatmap_plot, params=params)
+    spans = [(int(edges[i]), int(edges[i + 1])) for i in range(len(edges) - 1)]
+    kw = dict(plot=plot, show_plots=show_plots, save_plots=save_plots, output_folder=output_folder,
+              visualise_damaged_pixels_plot=visualise_damaged_pixels_plot,
+              plot_damaged_pixels_plot=plot_damaged_pixels_plot, plot_heatmap_plot=plot_heatmap_plot, params=params)
+
+    def collect(res):
         for store, series in zip(per_chunk, res):
             store.append(series)
+
+    # Double-buffered streaming: a second thread decodes chunk k+1 (into pinned memory) while chunk k is on
+    # the GPU, and chunk k+1 is enqueued before the host turns chunk k's integers into the float series.
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max_workers=1) as decoder:
+        nxt = decoder.submit(_load_chunk, video_filename, *spans[0]) if spans else None
+        pending = None
+        for idx, (start, end) in enumerate(spans):
+            chunk = nxt.result()
+            if idx + 1 < len(spans):
+                nxt = decoder.submit(_load_chunk, video_filename, *spans[idx + 1])
+            print(f"processing chunk {idx}: frames {start}–{end}")
+            done = _submit_chunk(chunk, idx, kw)
+            if pending is not None:
+                collect(pending())
+            pending = done
+        if pending is not None:
+            collect(pending())
     counts, clusters, sizes, brightness = (np.concatenate(s) for s in per_chunk)
     averages_counts = chunked_nanmean(counts, step)
     times = ((np.arange(len(averages_counts)) * step) + step / 2) / FPS
@@ -708,6 +776,7 @@ def main(video_filename, average_time=1.0, max_chunks=None, step_size=1000, plot
 for _n in _STAGES:
     _ORIG[_n] = globals()[_n]
 del _n
+_ORIG["detect_damaged_pixels"] = detect_damaged_pixels
 
 
 def _cli(argv=None):

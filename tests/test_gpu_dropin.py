@@ -228,3 +228,29 @@ def test_main_on_avi(ip, tmp_path):
     fn2 = str(tmp_path / "clip_bgr.avi")
     avi.write_avi(fn2, [np.repeat(f[:, :, None], 3, axis=2) for f in frames[:4]], fps=4.0)
     assert np.array_equal(np.stack(ip.load_video_frames(fn2)), frames[:4])
+
+
+def test_main_streams_chunks_like_the_sequential_driver(ip, tmp_path, monkeypatch):
+    """The double-buffered driver (decode thread + asynchronous chunks) returns exactly what chunk-by-chunk
+    calls of detect_damaged_pixels return, also with a partial last chunk and with a replaced stage."""
+    from image_processing_amd import avi, synth
+    frames = synth.chunk_numpy(5, 23, 72, 96, motion_at=(9,), hot=8.0, stuck=2)
+    fn = str(tmp_path / "clip.avi")
+    avi.write_avi(fn, list(frames), fps=5.0)
+    res = ip.main(fn, average_time=1.0, max_chunks=None, step_size=6)
+    series = [[], [], [], []]
+    for a in range(0, len(frames), 6):
+        for s, v in zip(series, ip.detect_damaged_pixels(frames[a:a + 6], 0)):
+            s.append(v)
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for key, e in zip(("averages_counts", "averages_clusters", "averages_size", "averages_brightness"), series):
+            assert _eq_nan(res[key], ip.chunked_nanmean(np.concatenate(e), 5)), key
+        # a replaced stage sends every chunk through the module-global detect_damaged_pixels
+        calls = []
+        orig = ip.compute_optical_flow_metric
+        monkeypatch.setattr(ip, "compute_optical_flow_metric", lambda fr: (calls.append(len(fr)), orig(fr))[1])
+        res2 = ip.main(fn, average_time=1.0, max_chunks=2, step_size=6)
+    assert calls == [6, 6]
+    assert _eq_nan(res2["averages_counts"], ip.chunked_nanmean(np.concatenate(series[0][:2]), 5))
