@@ -144,10 +144,13 @@ def load_video_frames(filename, frames_start=None, frames_end=None, grayscale=Tr
     if frames_start:
         cap.set(pos_prop, frames_start)
     frame_idx = frames_start or 0
+    # our own reader hands 8-bit streams over as they are stored (cv2 would expand them to grey-coded BGR and
+    # the luma conversion would give the same bytes back)
+    direct = grayscale and getattr(cap, "is_gray", lambda: False)()
     while cap.isOpened():
         if frames_end and frame_idx >= frames_end:
             break
-        ret, frame = cap.read()
+        ret, frame = cap.read_gray() if direct else cap.read()
         if not ret:
             break
         if grayscale and len(frame.shape) == 3:

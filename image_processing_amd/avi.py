@@ -178,6 +178,18 @@ class VideoCapture:
             f = np.repeat(f[:, :, None], 3, axis=2)
         return True, f
 
+    def is_gray(self):
+        """True for an 8-bit stream: read_gray() then returns the stored grey frames themselves (what
+        cvtColor(BGR2GRAY) gives back for the grey-coded BGR frames read() returns)."""
+        return self._r is not None and self._r.bpp == 8
+
+    def read_gray(self):
+        if self._r is None or self._pos >= self._r.frame_count:
+            return False, None
+        f = self._r.read(self._pos)
+        self._pos += 1
+        return True, f
+
     def release(self):
         if self._r is not None:
             self._r.close()

@@ -43,3 +43,27 @@ def test_rejects_compressed(tmp_path):
     open(fn, "wb").write(bytes(data))
     with pytest.raises(ValueError, match="uncompressed"):
         avi.AviReader(fn)
+
+
+def test_read_gray_returns_the_stored_frames(tmp_path):
+    import numpy as np
+    from image_processing_amd import avi
+    rng = np.random.default_rng(3)
+    frames = [rng.integers(0, 256, (13, 21), dtype=np.uint8) for _ in range(4)]
+    fn = str(tmp_path / "g.avi")
+    avi.write_avi(fn, frames, fps=10.0)
+    cap = avi.VideoCapture(fn)
+    assert cap.is_gray()
+    cap.set(avi.VideoCapture.CAP_PROP_POS_FRAMES, 1)
+    got = []
+    while True:
+        ok, f = cap.read_gray()
+        if not ok:
+            break
+        got.append(f)
+    cap.release()
+    assert len(got) == 3 and all(np.array_equal(a, b) for a, b in zip(got, frames[1:]))
+    avi.write_avi(fn, [np.repeat(f[:, :, None], 3, axis=2) for f in frames], fps=10.0)
+    cap = avi.VideoCapture(fn)
+    assert not cap.is_gray()
+    cap.release()
