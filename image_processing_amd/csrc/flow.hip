@@ -313,6 +313,58 @@ __global__ __launch_bounds__(256) void pyr_level_kernel(PyrArgs a)
 //      f64: the products are exact, so the fused multiply-add rounds exactly like the reference's mul + add.
 // Tiles are numbered frame-major and dealt to the 8 XCDs in contiguous ranges, so that vertically adjacent
 // tiles (which share 10 of 26 window rows) run on the same L2.
+// Levels 0 and 1 of the usual pyramid (3x3 Gaussian, then a copy or an exact 2x2 mean) when H and W are
+// multiples of 4: no LDS, one thread = a 4x4 block of blurred full-resolution pixels from its 6x6 source
+// window (three loads per source row, neighbours hit L1), same operation order as pyr_level_kernel<3>:
+// row pass S[0]*k1 + (S[-1]+S[1])*k2, column pass k1*T[0] + k2*(T[1]+T[-1]), mean (s00+s01+s10+s11)*0.25.
+template <int MODE>
+__global__ __launch_bounds__(256) void pyr3_kernel(PyrArgs a)
+{
+    const int bx = 4 * (blockIdx.x * 64 + (threadIdx.x & 63)), by = 4 * (blockIdx.y * 4 + (threadIdx.x >> 6));
+    if (bx >= a.W || by >= a.H) return;
+    const int f = blockIdx.z, fi = a.first + f;
+    const uint8_t *frame = fi < 0 ? a.extra : a.frames + (size_t)fi * a.H * a.W;
+    const float k1 = a.kt.k[1], k2 = a.kt.k[2];
+    float rp[6][4];
+#pragma unroll
+    for (int r = 0; r < 6; ++r) {
+        const uint8_t *row = frame + (size_t)reflect101(by - 1 + r, a.H) * a.W;
+        const uint32_t mid = *reinterpret_cast<const uint32_t *>(row + bx);
+        float p[6];
+        p[0] = (float)(bx > 0 ? (int)row[bx - 1] : (int)((mid >> 8) & 0xff));             // reflect-101: column -1 is column 1
+        p[1] = (float)(mid & 0xff); p[2] = (float)((mid >> 8) & 0xff);
+        p[3] = (float)((mid >> 16) & 0xff); p[4] = (float)(mid >> 24);
+        p[5] = (float)(bx + 4 < a.W ? (int)row[bx + 4] : (int)((mid >> 16) & 0xff));      // column W is column W-2
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            float v = p[c + 1] * k1;
+            v += (p[c] + p[c + 2]) * k2;
+            rp[r][c] = v;
+        }
+    }
+    float bl[4][4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            float v = k1 * rp[r + 1][c];
+            v += k2 * (rp[r + 2][c] + rp[r][c]);
+            bl[r][c] = v;
+        }
+    if (MODE == 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            *reinterpret_cast<float4 *>(a.out + ((size_t)f * a.lh + by + r) * a.lw + bx) = make_float4(bl[r][0], bl[r][1], bl[r][2], bl[r][3]);
+    } else {
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const float v0 = (bl[2 * r][0] + bl[2 * r][1] + bl[2 * r + 1][0] + bl[2 * r + 1][1]) * 0.25f;
+            const float v1 = (bl[2 * r][2] + bl[2 * r][3] + bl[2 * r + 1][2] + bl[2 * r + 1][3]) * 0.25f;
+            *reinterpret_cast<float2 *>(a.out + ((size_t)f * a.lh + (by >> 1) + r) * a.lw + (bx >> 1)) = make_float2(v0, v1);
+        }
+    }
+}
+
 // floats per frame of an expansion: 5 per pixel, rounded up so that every frame's float4 plane is 16-byte aligned
 __host__ __device__ inline size_t r_stride(size_t P) { return (5 * P + 3) & ~(size_t)3; }
 
@@ -953,6 +1005,11 @@ int launch_level_expansion(ipx_ctx *ctx, const LevelGeom &g, const uint8_t *fram
     const dim3 grid(8 * ((a.tiles_x * a.tiles_y * nf + 7) / 8)), block(256);
     const double pyr_bytes = (double)nf * ((double)pl->H * pl->W + 4.0 * g.lh * g.lw);
     if (ctx->prof.on) ipx_prof_begin(ctx, KID_PYR, pyr_bytes);
+    if (g.ksize == 3 && g.mode <= 1 && (pl->W & 3) == 0 && (pl->H & 3) == 0) {
+        const dim3 g3((pl->W / 4 + 63) / 64, (pl->H / 4 + 3) / 4, nf);
+        if (g.mode == 0) hipLaunchKernelGGL(pyr3_kernel<0>, g3, block, 0, ctx->stream, a);
+        else hipLaunchKernelGGL(pyr3_kernel<1>, g3, block, 0, ctx->stream, a);
+    } else
     switch (g.ksize) {
     case 3: hipLaunchKernelGGL(pyr_level_kernel<3>, grid, block, g.lds_bytes, ctx->stream, a); break;
     case 9: hipLaunchKernelGGL(pyr_level_kernel<9>, grid, block, g.lds_bytes, ctx->stream, a); break;
