@@ -6,6 +6,7 @@
   chunk is covered by size-independent properties (run-to-run bitwise determinism, sharded == unsharded,
   a chunk equals the concatenation of its frame-independent parts, counts invariant under a frame shuffle
   where the path is frame-independent);
+* configs[4]  3840x2160: a slice vs the oracle (frame dimensions, not throughput);
 * configs[3]  camera-motion-heavy sequence: the discard list and everything downstream of it.
 """
 import numpy as np
@@ -56,9 +57,18 @@ def test_config0_640x480_300_frames_static_camera(eng):
 
 def test_config1_1080p_slice_vs_oracle(eng):
     from image_processing_amd import synth
-    frames = synth.chunk_numpy(1080, 12, 1080, 1920, hot=120.0, stuck=8, blobs=4, motion_at=(5,), shift=9.0)
+    # 70 frames: two batches of frame pairs in the flow stage, ~2.3 M bit-plane words per labelling pass
+    frames = synth.chunk_numpy(1080, 70, 1080, 1920, hot=120.0, stuck=8, blobs=4, motion_at=(5, 40), shift=9.0)
     r, mid = _vs_oracle(eng, frames)
-    assert not r["keep"][5] and r["keep"][[0, 1, 2, 3, 4]].all()
+    assert not r["keep"][5] and not r["keep"][40] and r["keep"][[0, 1, 2, 3, 4]].all()
+
+
+def test_config4_4k_slice_vs_oracle(eng):
+    from image_processing_amd import synth
+    # few clusters: the oracle's cluster filter costs one full-frame pass per label, as the reference's does
+    frames = synth.chunk_numpy(2160, 5, 2160, 3840, hot=12.0, stuck=3, blobs=2, motion_at=(3,), shift=12.0)
+    r, mid = _vs_oracle(eng, frames)
+    assert not r["keep"][3] and np.nansum(r["total_counts"]) > 0
 
 
 def test_config3_camera_motion_heavy(eng):
