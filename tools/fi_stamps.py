@@ -4,8 +4,10 @@
   python tools/fi_stamps.py --build     here (CPU): compiles image_processing_amd/lib_stamps/libipx.so with -DIPX_FI_STAMPS
   python tools/fi_stamps.py             on the GPU box: runs one 1080p batch and prints cycles per step, wave and phase
 
-Producer waves (4-7): 0 = issue loads, 1 = B, 2 = wait at barrier X, 3 = finish + ring store, 4 = wait at barrier Y.
-Consumer waves (0-3): 1 = B, 2 = wait X, 3 = C, 4 = wait Y.
+Producer waves (4-7): 0 = finish + store the first of the thread's two matrix rows (includes waiting for its loads),
+1 = issue the loads that replace it, 2 = finish + store the second row, 3 = issue its replacement, 4 = wait at the
+step barrier.  Consumer waves (0-3): 1 = B (vertical running sums), 2 = wait for the other consumers, 3 = C
+(horizontal sums + solve + store), 4 = wait at the step barrier.
 """
 import ctypes as C
 import os
@@ -14,8 +16,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-EXP = ""
-LIBDIR = os.path.join(ROOT, "image_processing_amd", "lib_stamps" + EXP)
+LIBDIR = os.path.join(ROOT, "image_processing_amd", "lib_stamps")
 LIB = os.path.join(LIBDIR, "libipx.so")
 
 
@@ -25,7 +26,7 @@ def build():
     objs = []
     for s in b.SOURCES:
         obj = os.path.join(LIBDIR, s.replace(".hip", ".o"))
-        subprocess.check_call([b._hipcc()] + b.FLAGS + ["-DIPX_FI_STAMPS"] + (["-DFI_EXP=" + EXP] if EXP else []) + ["-c", os.path.join(b.CSRC, s), "-o", obj])
+        subprocess.check_call([b._hipcc()] + b.FLAGS + ["-DIPX_FI_STAMPS", "-c", os.path.join(b.CSRC, s), "-o", obj])
         objs.append(obj)
     subprocess.check_call([b._hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs)
     print(LIB)
