@@ -727,9 +727,13 @@ def _submit_chunk(chunk, idx, kw):
 
 def main(video_filename, average_time=1.0, max_chunks=None, step_size=1000, plot=False, show_plots=False,
          save_plots=False, output_folder="results", visualise_damaged_pixels_plot=True, plot_damaged_pixels_plot=True,
-         plot_heatmap_plot=True, params=None):
+         plot_heatmap_plot=True, params=None, *, checkpoint_folder=None):
     """ip.py:1136-1247: process a video in chunks of ``step_size`` frames and return the per-window
-    averages (``average_time`` seconds each) of the four per-frame series, plus the window mid-times."""
+    averages (``average_time`` seconds each) of the four per-frame series, plus the window mid-times.
+
+    ``checkpoint_folder`` (not in the reference, which keeps everything in RAM until the end): every finished
+    chunk's four series are written to ``chunk_<start>_<end>.npz`` there, and a chunk whose file already
+    exists is neither decoded nor processed again (resume after an interruption; no plots for such chunks)."""
     num_frames, FPS = _video_info(video_filename)
     edges = np.arange(0, num_frames, step_size)
     if edges[-1] != num_frames:
@@ -743,27 +747,55 @@ def main(video_filename, average_time=1.0, max_chunks=None, step_size=1000, plot
               visualise_damaged_pixels_plot=visualise_damaged_pixels_plot,
               plot_damaged_pixels_plot=plot_damaged_pixels_plot, plot_heatmap_plot=plot_heatmap_plot, params=params)
 
-    def collect(res):
+    def ckpt_path(span):
+        return os.path.join(checkpoint_folder, "chunk_%09d_%09d.npz" % span) if checkpoint_folder else None
+
+    def from_checkpoint(span):
+        path = ckpt_path(span)
+        if path and os.path.exists(path):
+            with np.load(path) as z:
+                if int(z["n_frames"]) == span[1] - span[0]:
+                    return tuple(z[k] for k in ("total_counts", "cluster_counts", "avg_sizes", "avg_brightnesses"))
+        return None
+
+    def collect(res, span=None):
         for store, series in zip(per_chunk, res):
             store.append(series)
+        path = ckpt_path(span) if span else None
+        if path and not os.path.exists(path):
+            os.makedirs(checkpoint_folder, exist_ok=True)
+            tmp = path + ".tmp.npz"
+            np.savez(tmp, total_counts=res[0], cluster_counts=res[1], avg_sizes=res[2], avg_brightnesses=res[3],
+                     n_frames=span[1] - span[0])
+            os.replace(tmp, path)
 
     # Double-buffered streaming: a second thread decodes chunk k+1 (into pinned memory) while chunk k is on
     # the GPU, and chunk k+1 is enqueued before the host turns chunk k's integers into the float series.
     from concurrent.futures import ThreadPoolExecutor
+    saved = [from_checkpoint(sp) for sp in spans]
+    todo = [i for i in range(len(spans)) if saved[i] is None]
     with ThreadPoolExecutor(max_workers=1) as decoder:
-        nxt = decoder.submit(_load_chunk, video_filename, *spans[0]) if spans else None
-        pending = None
+        nxt = decoder.submit(_load_chunk, video_filename, *spans[todo[0]]) if todo else None
+        pending = None                                   # (completion, span) of the chunk on the GPU
         for idx, (start, end) in enumerate(spans):
+            if saved[idx] is not None:
+                if pending is not None:                  # keep the series in chunk order
+                    collect(pending[0](), pending[1])
+                    pending = None
+                print(f"chunk {idx}: frames {start}–{end} taken from {ckpt_path(spans[idx])}")
+                collect(saved[idx])
+                continue
             chunk = nxt.result()
-            if idx + 1 < len(spans):
-                nxt = decoder.submit(_load_chunk, video_filename, *spans[idx + 1])
+            later = [i for i in todo if i > idx]
+            if later:
+                nxt = decoder.submit(_load_chunk, video_filename, *spans[later[0]])
             print(f"processing chunk {idx}: frames {start}–{end}")
             done = _submit_chunk(chunk, idx, kw)
             if pending is not None:
-                collect(pending())
-            pending = done
+                collect(pending[0](), pending[1])
+            pending = (done, spans[idx])
         if pending is not None:
-            collect(pending())
+            collect(pending[0](), pending[1])
     counts, clusters, sizes, brightness = (np.concatenate(s) for s in per_chunk)
     averages_counts = chunked_nanmean(counts, step)
     times = ((np.arange(len(averages_counts)) * step) + step / 2) / FPS
@@ -798,6 +830,7 @@ def _cli(argv=None):
     parser.add_argument("-cp", "--chunk_plots", help="(Default=True) True or False: per-chunk plots")
     parser.add_argument("-ap", "--average_plots", help="(Default=True) True or False: final averages plot")
     parser.add_argument("-of", "--output_folder", help="Location of where saved plots are saved")
+    parser.add_argument("-ckf", "--checkpoint_folder", help="(not in the reference) per-chunk .npz results; finished chunks are skipped on a rerun")
     for short, name in (("-ct", "consecutive_threshold"), ("-bt", "brightness_threshold"), ("-ft", "flow_threshold"),
                         ("-st", "static_threshold"), ("-mncs", "min_cluster_size"), ("-mxcs", "max_cluster_size"),
                         ("-mnc", "min_circularity"), ("-swr", "sliding_window_radius"), ("-np", "number_of_plots")):
@@ -835,7 +868,8 @@ def _cli(argv=None):
         output_folder=output_folder,
         visualise_damaged_pixels_plot=flag(args.visualise_damaged_pixels_plot, False),
         plot_damaged_pixels_plot=flag(args.plot_damaged_pixels_plot, True),
-        plot_heatmap_plot=flag(args.plot_heatmap_plot, True), params=params)
+        plot_heatmap_plot=flag(args.plot_heatmap_plot, True), params=params,
+        checkpoint_folder=args.checkpoint_folder or None)
     if flag(args.average_plots, True) and HAS_MATPLOTLIB:
         plot_all_chunks(results["averages_counts"], results["averages_clusters"], results["averages_size"],
                         results["averages_brightness"], results["times"], show_plots=show_plots,

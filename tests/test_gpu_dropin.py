@@ -254,3 +254,27 @@ def test_main_streams_chunks_like_the_sequential_driver(ip, tmp_path, monkeypatc
         res2 = ip.main(fn, average_time=1.0, max_chunks=2, step_size=6)
     assert calls == [6, 6]
     assert _eq_nan(res2["averages_counts"], ip.chunked_nanmean(np.concatenate(series[0][:2]), 5))
+
+
+def test_main_checkpoints_and_resumes(ip, tmp_path, monkeypatch):
+    from image_processing_amd import avi, synth
+    frames = synth.chunk_numpy(9, 17, 64, 80, hot=6.0, stuck=2)
+    fn = str(tmp_path / "clip.avi")
+    avi.write_avi(fn, list(frames), fps=4.0)
+    ck = str(tmp_path / "ck")
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        first = ip.main(fn, max_chunks=None, step_size=5, checkpoint_folder=ck)
+        import os
+        names = sorted(os.listdir(ck))
+        assert len(names) == 4 and all(n.endswith(".npz") for n in names)
+        os.remove(os.path.join(ck, names[2]))                      # only this chunk has to be decoded again
+        loaded = []
+        orig = ip.load_video_frames
+        monkeypatch.setattr(ip, "load_video_frames", lambda f, frames_start=None, frames_end=None, grayscale=True:
+                            (loaded.append((frames_start, frames_end)), orig(f, frames_start, frames_end, grayscale))[1])
+        again = ip.main(fn, max_chunks=None, step_size=5, checkpoint_folder=ck)
+    assert loaded == [(10, 15)]
+    for k in first:
+        assert _eq_nan(first[k], again[k]), k
