@@ -628,6 +628,7 @@ __global__ __launch_bounds__(FI_THREADS, 4) void flow_iter_kernel(const FiArgs a
 
     const int ac = tid & (FI_MC - 1);                    // matrix column of phases A and B
     int ax = x0 - FI_M + ac;
+    const bool col_used = ax <= w - 1 + FI_M;            // matrix columns further right feed no output of the image
     ax = ax < 0 ? 0 : (ax > w - 1 ? w - 1 : ax);
     auto clamp_row = [&](int j) { return j < 0 ? 0 : (j > h - 1 ? h - 1 : j); };
     // matrix row j (unclamped) lives in ring slot (j - ys + 8) % RING
@@ -676,7 +677,7 @@ __global__ __launch_bounds__(FI_THREADS, 4) void flow_iter_kernel(const FiArgs a
         const float2 d = vec_finish(vec_issue(y));
         UmIn in;
         float m[5];
-        um_load(rR, FS, P16, d, ax, y, h, w, in);
+        um_load(rR, FS, P16, d, ax, y, h, w, in, col_used);
         um_finish(in, d, ax, y, h, w, m);
         ring_store(j, m);
     }
@@ -749,8 +750,8 @@ __global__ __launch_bounds__(FI_THREADS, 4) void flow_iter_kernel(const FiArgs a
         {
             const int j0 = ys + FI_M + FI_G + prow, j1 = j0 + 2;     // rows of step 1
             const bool more = ys + FI_G < ye;
-            um_load(rR, FS, P16, d0, ax, clamp_row(j0), h, w, in0, more);
-            um_load(rR, FS, P16, d1, ax, clamp_row(j1), h, w, in1, more);
+            um_load(rR, FS, P16, d0, ax, clamp_row(j0), h, w, in0, more && col_used);
+            um_load(rR, FS, P16, d1, ax, clamp_row(j1), h, w, in1, more && col_used);
             dv0 = vec_issue(clamp_row(j0 + FI_G));
             dv1 = vec_issue(clamp_row(j1 + FI_G));
         }
@@ -764,14 +765,14 @@ __global__ __launch_bounds__(FI_THREADS, 4) void flow_iter_kernel(const FiArgs a
             if (more) ring_store(j0, m);
             FI_STAMP(0);
             d0 = vec_finish(dv0);
-            um_load(rR, FS, P16, d0, ax, clamp_row(j0 + FI_G), h, w, in0, more2);
+            um_load(rR, FS, P16, d0, ax, clamp_row(j0 + FI_G), h, w, in0, more2 && col_used);
             dv0 = vec_issue(clamp_row(j0 + 2 * FI_G));
             FI_STAMP(1);
             um_finish(in1, d1, ax, clamp_row(j1), h, w, m);
             if (more) ring_store(j1, m);
             FI_STAMP(2);
             d1 = vec_finish(dv1);
-            um_load(rR, FS, P16, d1, ax, clamp_row(j1 + FI_G), h, w, in1, more2);
+            um_load(rR, FS, P16, d1, ax, clamp_row(j1 + FI_G), h, w, in1, more2 && col_used);
             dv1 = vec_issue(clamp_row(j1 + 2 * FI_G));
             FI_STAMP(3);
             fi_barrier();                                // ring rows of the next step written
