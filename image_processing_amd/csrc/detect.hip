@@ -42,19 +42,22 @@ __device__ __forceinline__ uint32_t load4(const uint8_t *row, int x, int W, bool
 }
 
 // _find_background for one pixel from its n temporal neighbours (byte j of v[0..n)).
-template <int MAXN>
+// FULL: n == MAXN is known at compile time (every frame that is 'radius' away from both chunk ends), so the
+// neighbour loops carry no predication.
+template <int MAXN, bool FULL>
 __device__ __forceinline__ float background_px(const uint32_t (&v)[MAXN], int n, int j, double coeff)
 {
+    if (FULL) n = MAXN;
     int S = 0;
 #pragma unroll
     for (int k = 0; k < MAXN; ++k)
-        if (k < n) S += (v[k] >> (8 * j)) & 0xff;
+        if (FULL || k < n) S += (v[k] >> (8 * j)) & 0xff;
     const float fn = (float)n;
     const float mean = (float)S / fn;            // == f32(f64(S)/n): tests/test_oracle_known_answers.py
     double acc = 0.0;
 #pragma unroll
     for (int k = 0; k < MAXN; ++k)
-        if (k < n) {
+        if (FULL || k < n) {
             const float diff = (float)((v[k] >> (8 * j)) & 0xff) - mean;
             const float d2 = diff * diff;
             acc += (double)d2;
@@ -64,7 +67,7 @@ __device__ __forceinline__ float background_px(const uint32_t (&v)[MAXN], int n,
     int Si = 0, c = 0;
 #pragma unroll
     for (int k = 0; k < MAXN; ++k)
-        if (k < n) {
+        if (FULL || k < n) {
             const int b = (v[k] >> (8 * j)) & 0xff;
             if ((double)b <= thr) { Si += b; ++c; }
         }
@@ -185,6 +188,7 @@ __global__ __launch_bounds__(256) void detect_kernel(DetectArgs a)
     const int lo = max(0, fi - a.radius), hi = min(a.n, fi + a.radius + 1);
     const int nn = hi - lo - 1;                              // neighbours (centre excluded)
     const int xq = (tid & 15) * 4;
+    const bool full = nn == MAXN;                            // workgroup-uniform
     unsigned int c_lt = 0, c_gt = 0;
 #pragma unroll 1
     for (int step = 0; step < 4; ++step) {
@@ -206,7 +210,7 @@ __global__ __launch_bounds__(256) void detect_kernel(DetectArgs a)
             for (int j = 0; j < 4; ++j) {
                 if (gx + j < W) {
                     const int pix = (cen >> (8 * j)) & 0xff;
-                    const float bg = background_px<MAXN>(v, nn, j, a.coeff);
+                    const float bg = full ? background_px<MAXN, true>(v, nn, j, a.coeff) : background_px<MAXN, false>(v, nn, j, a.coeff);
                     if (a.bg_out) a.bg_out[(size_t)gy * W + gx + j] = bg;
                     const float thr = damage_threshold_f32(bg);
                     const bool dmg = ((float)pix > thr) && (900 * pix > vs[j]);

@@ -55,6 +55,7 @@ struct LevelGeom {
 
 struct PolyConst {
     float g[POLY_N + 1], xg[POLY_N + 1], xxg[POLY_N + 1];
+    double gd[POLY_N + 1], xxgd[POLY_N + 1];             // g and xxg widened once on the host
     double ig11, ig03, ig33, ig55;
 };
 
@@ -128,7 +129,7 @@ void poly_prepare(int n, double sigma, PolyConst &pc)
     pc.ig03 = (b * d - b * c) / det;
     pc.ig33 = (a * c - b * b) / det;
     pc.ig55 = 1.0 / G55;
-    for (int k = 0; k <= n; ++k) { pc.g[k] = g[k]; pc.xg[k] = xg[k]; pc.xxg[k] = xxg[k]; }
+    for (int k = 0; k <= n; ++k) { pc.g[k] = g[k]; pc.xg[k] = xg[k]; pc.xxg[k] = xxg[k]; pc.gd[k] = (double)g[k]; pc.xxgd[k] = (double)xxg[k]; }
 }
 
 // cv::resize(INTER_LINEAR) coordinate tables for one axis: dst length dn from src length sn.
@@ -420,8 +421,8 @@ __global__ __launch_bounds__(256) void polyexp_kernel(const float *I, int h, int
         for (int j = 1; j <= POLY_N; ++j) {
             const double tg = r0[j] + r0[-j];
             const float g0 = pc.g[j];
-            b1 = __builtin_fma(tg, (double)g0, b1);
-            b4 = __builtin_fma(tg, (double)pc.xxg[j], b4);
+            b1 = __builtin_fma(tg, pc.gd[j], b1);
+            b4 = __builtin_fma(tg, pc.xxgd[j], b4);
             b2 += (r0[j] - r0[-j]) * pc.xg[j];
             b3 += (r1[j] + r1[-j]) * g0;
             b6 += (r1[j] - r1[-j]) * pc.xg[j];
