@@ -736,7 +736,11 @@ __global__ __launch_bounds__(FI_THREADS, 4) void flow_iter_kernel(const FiArgs a
     auto consumers_sync = [&]() {
         flag_target += 4;
         if ((tid & 63) == 0) __hip_atomic_fetch_add(s_flag, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-        while (__hip_atomic_load(s_flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < flag_target) __builtin_amdgcn_s_sleep(1);
+        // every consumer wave posts once per step, so the wait ends; the bound only keeps a future protocol
+        // error from hanging the GPU (it is ~10 s of polling)
+        unsigned spins = 0;
+        while (__hip_atomic_load(s_flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < flag_target && ++spins < (1u << 27))
+            __builtin_amdgcn_s_sleep(1);
     };
 
 #ifdef IPX_FI_STAMPS
