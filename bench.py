@@ -168,6 +168,20 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
+    copy_gbs = None
+    if rank == 0:
+        # measured device-copy ceiling beside the 8 TB/s spec: 2 GB read + 2 GB written per copy
+        src = chunks[0]
+        dst = torch.empty_like(src)
+        dst.copy_(src)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5):
+            dst.copy_(src)
+        e1.record()
+        torch.cuda.synchronize()
+        copy_gbs = 5 * 2.0 * src.numel() / (e0.elapsed_time(e1) * 1e-3) / 1e9
+        del dst
     if rank == 0:
         workload = "%dx%d u8, %d-frame chunks%s" % (W, H, n_total, ", camera motion" if args.motion else "")
         roof = None
@@ -186,7 +200,8 @@ def main():
             roof = dict(bound="hbm", kernel=dom, achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit="GB/s",
                         frac=round(ach / HBM_PEAK_GBS, 4), traffic=traffic,
                         bytes_per_launch=round(v["bytes"] / v["launches"]), avg_launch_us=round(1e3 * v["ms"] / v["launches"], 2),
-                        launches=v["launches"], share_of_gpu_time=round(v["ms"] / tot_ms, 4))
+                        launches=v["launches"], share_of_gpu_time=round(v["ms"] / tot_ms, 4),
+                        device_copy_gbs=round(copy_gbs, 1))
         cpu = None
         if world == 1 and args.cpu_frames > 0:
             cpu = cpu_baseline(chunks[args.warmup % 2][:args.cpu_frames].cpu().numpy())
