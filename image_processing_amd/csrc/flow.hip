@@ -16,10 +16,11 @@
 // sums instead of running sums) and the mean magnitude (f64 tree instead of numpy's f32
 // pairwise sum).
 //
-// MI355X design: a batch of B consecutive pairs is processed per launch (grid.z = frame or
-// pair) so that the coarse pyramid levels still fill 256 CUs; the polynomial expansion of a
-// frame is computed once and serves both pairs it belongs to; expansions and matrices are
-// planar ([channel][y][x]) so that every wave reads and writes contiguous 256-byte rows.
+// MI355X design: a batch of up to 256 consecutive pairs is processed per launch so that the coarse pyramid
+// levels still fill 256 CUs; the polynomial expansion of a frame is computed once and serves both pairs it
+// belongs to; the update matrices live only in LDS (flow_iter_kernel); upsampling between levels and the
+// magnitude reduction are variants of the iteration kernel; workgroup ids are mapped so that the pairs that
+// share an expansion run on the same XCD (one L2).
 #include "ipx_internal.h"
 #include <math.h>
 #include <float.h>
