@@ -181,9 +181,9 @@ static int prof_fold(ipx_ctx *ctx)
 {
     ipx_prof &pr = ctx->prof;
     if (pr.nrecs == 0) return IPX_OK;
-    IPX_CHECK_HIP(hipStreamSynchronize(ctx->stream));
     for (int i = 0; i < pr.nrecs; ++i) {
         float ms = 0.f;
+        IPX_CHECK_HIP(hipEventSynchronize(pr.recs[i].e1));      // waits for this launch only
         IPX_CHECK_HIP(hipEventElapsedTime(&ms, pr.recs[i].e0, pr.recs[i].e1));
         pr.ms[pr.recs[i].kid] += ms;
         pr.bytes[pr.recs[i].kid] += pr.recs[i].bytes;

@@ -18,7 +18,9 @@
 //
 // MI355X design: a batch of up to 256 consecutive pairs is processed per launch so that the coarse pyramid
 // levels still fill 256 CUs; the polynomial expansion of a frame is computed once and serves both pairs it
-// belongs to; the update matrices live only in LDS (flow_iter_kernel); upsampling between levels and the
+// belongs to (computing the expansions of batch b+1 on a side stream under the iterations of batch b was
+// tried: the kernels overlap but slow each other down by the same amount); the update matrices live only in
+// LDS (flow_iter_kernel); upsampling between levels and the
 // magnitude reduction are variants of the iteration kernel; workgroup ids are mapped so that the pairs that
 // share an expansion run on the same XCD (one L2).
 #include "ipx_internal.h"
