@@ -56,7 +56,10 @@ __global__ void fill_plane_kernel(uint64_t *out, int H, int W, int wpr)
     out[w] = valid >= 64 ? ~0ull : (1ull << valid) - 1;
 }
 
-// heat = sum clean, valid = sum !(frame > bt & !clean); one lane owns 4 consecutive pixels.
+// heat = sum clean, valid = sum !(frame > bt & !clean); one lane owns 4 consecutive pixels of a group of
+// SM_GROUP frames (blockIdx.z) and adds its partial counts to the maps (zeroed by the caller; integer adds,
+// so the order does not matter).  A lane that walked all n frames alone was bound by load latency.
+constexpr int SM_GROUP = 64;
 __global__ void static_maps_kernel(const uint8_t *frames, const uint64_t *raw, const uint64_t *pers,
                                    const uint8_t *keep, int n, int H, int W, int wpr, int frame_gt,
                                    int32_t *heat, int32_t *valid)
@@ -64,6 +67,7 @@ __global__ void static_maps_kernel(const uint8_t *frames, const uint64_t *raw, c
     const int xq = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
     const int y = blockIdx.y;
     if (xq >= W) return;
+    const int i0 = blockIdx.z * SM_GROUP, i1 = min(n, i0 + SM_GROUP);
     const size_t words = (size_t)H * wpr;
     const size_t wi = (size_t)y * wpr + (xq >> 6);
     const int sh = xq & 63;
@@ -72,7 +76,8 @@ __global__ void static_maps_kernel(const uint8_t *frames, const uint64_t *raw, c
     const size_t P = (size_t)H * W;
     const uint8_t *px = frames + (size_t)y * W + xq;
     int hc[4] = {0, 0, 0, 0}, vc[4] = {0, 0, 0, 0};
-    for (int i = 0; i < n; ++i) {
+#pragma unroll 4
+    for (int i = i0; i < i1; ++i) {
         uint32_t f;
         if (aligned) f = *reinterpret_cast<const uint32_t *>(px + (size_t)i * P);
         else {
@@ -92,8 +97,8 @@ __global__ void static_maps_kernel(const uint8_t *frames, const uint64_t *raw, c
 #pragma unroll
     for (int j = 0; j < 4; ++j)
         if (xq + j < W) {
-            heat[(size_t)y * W + xq + j] = hc[j];
-            valid[(size_t)y * W + xq + j] = vc[j];
+            if (hc[j]) atomicAdd(&heat[(size_t)y * W + xq + j], hc[j]);
+            if (vc[j]) atomicAdd(&valid[(size_t)y * W + xq + j], vc[j]);
         }
 }
 
@@ -239,7 +244,9 @@ extern "C" int ipx_static_maps(ipx_ctx *ctx, const uint8_t *frames, const uint64
     if (int e = ipx_ctx_enter(ctx)) return e;
     const ipx_derived d = ipx_derive(ctx->p);
     const int quads = (W + 3) / 4;
-    const dim3 grid((quads + 63) / 64, H), block(64);
+    const dim3 grid((quads + 63) / 64, H, (n + SM_GROUP - 1) / SM_GROUP), block(64);
+    IPX_CHECK_HIP(hipMemsetAsync(heat, 0, sizeof(int32_t) * (size_t)H * W, ctx->stream));
+    IPX_CHECK_HIP(hipMemsetAsync(valid, 0, sizeof(int32_t) * (size_t)H * W, ctx->stream));
     IPX_LAUNCH(ctx, KID_STATIC_MAPS, (double)n * ((double)H * W + (double)H * ipx_wpr(W) * 8) + 8.0 * H * W + (double)H * ipx_wpr(W) * 8, static_maps_kernel, grid, block, frames, raw_bits, persistent_bits, keep,
                        n, H, W, ipx_wpr(W), d.frame_gt, heat, valid);
     IPX_LAUNCH_CHECK();
