@@ -422,7 +422,7 @@ int ccl_batch(const Plane &pl, int count, size_t per_plane_bytes, size_t budget)
     return (int)b;
 }
 
-constexpr size_t CCL_BUDGET = (size_t)1 << 30;
+constexpr size_t CCL_BUDGET = (size_t)8 << 30;     // ~490 planes of 1080p per labelling batch
 
 }  // namespace
 
