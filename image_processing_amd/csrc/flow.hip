@@ -645,11 +645,14 @@ __global__ __launch_bounds__(FI_THREADS, 4) void flow_iter_kernel(const FiArgs a
         for (int ch = 0; ch < 5; ++ch) dst[ch * FI_MC] = m[ch];
     };
     // flow vector of pixel (ax, row): the loads (vec_issue) are kept in flight across most of a step
-    int usx = 0, usx1 = 0; float ua1 = 0.f; bool uedge = false;
+    // (the two horizontal taps are neighbours: one 16-byte load per coarse row; at the right edge, where the
+    // reference uses the last sample alone, the pair ends at it)
+    struct FiTaps { float2 l, r; };                     // 8-byte aligned
+    int usx = 0; float ua1 = 0.f; bool uedge = false;
     if (IN == 2) {
         usx = a.x_ofs[ax]; ua1 = a.x_a[ax];
         uedge = usx >= a.sw - 1;
-        usx1 = uedge ? usx : usx + 1;
+        usx = max(0, min(usx, a.sw - 2));
     }
     auto vec_issue = [&](int row) {
         FiVec v;
@@ -658,14 +661,15 @@ __global__ __launch_bounds__(FI_THREADS, 4) void flow_iter_kernel(const FiArgs a
         } else if (IN == 2) {
             const float2 *S0 = fin + (size_t)a.y_ofs[2 * row] * a.sw, *S1 = fin + (size_t)a.y_ofs[2 * row + 1] * a.sw;
             v.b1 = a.y_b[row];
-            v.p00 = S0[usx]; v.p01 = S0[usx1]; v.p10 = S1[usx]; v.p11 = S1[usx1];
+            const FiTaps t0 = *reinterpret_cast<const FiTaps *>(S0 + usx), t1 = *reinterpret_cast<const FiTaps *>(S1 + usx);
+            v.p00 = t0.l; v.p01 = t0.r; v.p10 = t1.l; v.p11 = t1.r;
         }
         return v;
     };
     auto vec_finish = [&](const FiVec &v) {
         if (IN == 0) return v.p00;
         if (IN == 1) return make_float2(0.f, 0.f);
-        float2 h0 = v.p00, h1 = v.p10, o;
+        float2 h0 = v.p01, h1 = v.p11, o;
         if (!uedge) {
             const float a1 = ua1, a0 = 1.f - a1;
             h0.x = v.p00.x * a0 + v.p01.x * a1; h0.y = v.p00.y * a0 + v.p01.y * a1;
