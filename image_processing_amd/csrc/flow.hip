@@ -255,9 +255,27 @@ __global__ __launch_bounds__(256) void pyr_level_kernel(PyrArgs a)
     for (int s = tid; s < nsamp; s += 256)
         s_col[s] = (ns == 1 ? a.xs2[2 * (dx0 + s)] : a.xs2[2 * (dx0 + (s >> 1)) + (s & 1)]) - c_org;
     __syncthreads();
-    // 2. row pass: wave -> sample, lane -> staged row
+    // 2. row pass: wave -> sample, lane -> staged row.  The two samples of a level pixel are usually
+    // neighbouring columns: they are then evaluated from one set of KS+1 LDS reads (same taps, same order).
+    const bool paired = KS > 5 && ns == 2;
+    for (int sp = wv; paired && sp < ndx; sp += 4) {
+        const int c0 = s_col[2 * sp], c1 = s_col[2 * sp + 1];
+        if (c1 != c0 + 1) continue;
+        for (int r = lane; r < nrows; r += 64) {
+            const float *S = s_src + r * a.src_pitch + c0 - R;
+            float x[KS + 1];
+#pragma unroll
+            for (int i = 0; i <= KS; ++i) x[i] = S[i];
+            float v0 = x[0] * a.kt.k[0], v1 = x[1] * a.kt.k[0];
+#pragma unroll
+            for (int i = 1; i < KS; ++i) { v0 += x[i] * a.kt.k[i]; v1 += x[i + 1] * a.kt.k[i]; }
+            s_tmp[r * a.tmp_pitch + 2 * sp] = v0;
+            s_tmp[r * a.tmp_pitch + 2 * sp + 1] = v1;
+        }
+    }
     for (int s = wv; s < nsamp; s += 4) {
         const int cc = s_col[s];
+        if (paired && s_col[s ^ 1] == cc + 1 - 2 * (s & 1)) continue;      // done above
         for (int r = lane; r < nrows; r += 64) {
             const float *S = s_src + r * a.src_pitch + cc;
             float v;
@@ -282,6 +300,20 @@ __global__ __launch_bounds__(256) void pyr_level_kernel(PyrArgs a)
         for (int j = 1; j <= R; ++j) v += a.kt.k[R + j] * (T[j * a.tmp_pitch] + T[-j * a.tmp_pitch]);
         return v;
     };
+    // the two row samples of a level pixel are usually neighbouring rows: both column passes from KS+1 reads
+    auto col_pass2 = [&](int ra, int rb, int s, float &va, float &vb) {
+        if (KS <= 5 || rb != ra + 1) { va = col_pass(ra, s); vb = col_pass(rb, s); return; }
+        const float *T = s_tmp + (ra - R) * a.tmp_pitch + s;
+        float t[KS + 1];
+#pragma unroll
+        for (int i = 0; i <= KS; ++i) t[i] = T[i * a.tmp_pitch];
+        va = a.kt.k[R] * t[R]; vb = a.kt.k[R] * t[R + 1];
+#pragma unroll
+        for (int j = 1; j <= R; ++j) {
+            va += a.kt.k[R + j] * (t[R + j] + t[R - j]);
+            vb += a.kt.k[R + j] * (t[R + 1 + j] + t[R + 1 - j]);
+        }
+    };
     for (int idx = tid; idx < a.tox * ndy; idx += 256) {
         const int dyl = idx / a.tox, dxl = idx - dyl * a.tox;
         if (dxl >= ndx) continue;
@@ -291,18 +323,19 @@ __global__ __launch_bounds__(256) void pyr_level_kernel(PyrArgs a)
         if (a.mode == 0) {
             v = col_pass(ra, dxl);
         } else if (a.mode == 1) {
-            const float s00 = col_pass(ra, 2 * dxl), s01 = col_pass(ra, 2 * dxl + 1);
-            const float s10 = col_pass(rb, 2 * dxl), s11 = col_pass(rb, 2 * dxl + 1);
+            float s00, s01, s10, s11;
+            col_pass2(ra, rb, 2 * dxl, s00, s10);
+            col_pass2(ra, rb, 2 * dxl + 1, s01, s11);
             v = (s00 + s01 + s10 + s11) * 0.25f;
         } else {
             const float a1 = a.x_a[dx], a0 = 1.f - a1, b1 = a.y_b[dy], b0 = 1.f - b1;
             float h0, h1;
-            if (a.xs2[2 * dx] >= a.W - 1) {                   // right edge: single tap
-                h0 = col_pass(ra, 2 * dxl);
-                h1 = col_pass(rb, 2 * dxl);
-            } else {
-                h0 = col_pass(ra, 2 * dxl) * a0 + col_pass(ra, 2 * dxl + 1) * a1;
-                h1 = col_pass(rb, 2 * dxl) * a0 + col_pass(rb, 2 * dxl + 1) * a1;
+            col_pass2(ra, rb, 2 * dxl, h0, h1);
+            if (a.xs2[2 * dx] < a.W - 1) {                    // (right edge: single tap)
+                float g0, g1;
+                col_pass2(ra, rb, 2 * dxl + 1, g0, g1);
+                h0 = h0 * a0 + g0 * a1;
+                h1 = h1 * a0 + g1 * a1;
             }
             v = h0 * b0 + h1 * b1;
         }
