@@ -41,19 +41,35 @@ __device__ __forceinline__ uint32_t load4(const uint8_t *row, int x, int W, bool
     return v;
 }
 
-// _find_background for one pixel from its n temporal neighbours (byte j of v[0..n)).
+// Divisions without the IEEE divide sequence, bit-exact all the same:
+// * f64: for y = RN(1/b), q = RN(a*y) corrected twice by q += (a - b*q)*y (the residual is exact in an fma).
+//   The first correction makes q faithful, the second is then correctly rounded (Markstein's theorem).
+// * f32 quotients of a 24-bit a by an integer b <= 255: RN32(RN64(a * RN64(1/b))).  a/b is never closer
+//   than 2^-32 (relative) to a midpoint between two floats unless it is a float itself, and the f64 product
+//   is off by less than 2^-51: the final rounding cannot differ.  (tests/test_abi_and_host.py walks through
+//   every S/n and Si/c, and a sample of bg/255.)
+__device__ __forceinline__ double div_by(double a, double b, double y)
+{
+    double q = a * y;
+    double r = __builtin_fma(-b, q, a);
+    q = __builtin_fma(r, y, q);
+    r = __builtin_fma(-b, q, a);
+    return __builtin_fma(r, y, q);
+}
+
+// _find_background for one pixel from its n temporal neighbours (byte j of v[0..n)); rcp[i] = 1.0 / i.
 // FULL: n == MAXN is known at compile time (every frame that is 'radius' away from both chunk ends), so the
 // neighbour loops carry no predication.
 template <int MAXN, bool FULL>
-__device__ __forceinline__ float background_px(const uint32_t (&v)[MAXN], int n, int j, double coeff)
+__device__ __forceinline__ float background_px(const uint32_t (&v)[MAXN], int n, int j, double coeff, const double *rcp)
 {
     if (FULL) n = MAXN;
+    const double yn = FULL ? 1.0 / (double)MAXN : rcp[n];
     int S = 0;
 #pragma unroll
     for (int k = 0; k < MAXN; ++k)
         if (FULL || k < n) S += (v[k] >> (8 * j)) & 0xff;
-    const float fn = (float)n;
-    const float mean = (float)S / fn;            // == f32(f64(S)/n): tests/test_oracle_known_answers.py
+    const float mean = (float)((double)S * yn);  // == (float)S / (float)n == f32(f64(S)/n)
     double acc = 0.0;
 #pragma unroll
     for (int k = 0; k < MAXN; ++k)
@@ -62,21 +78,23 @@ __device__ __forceinline__ float background_px(const uint32_t (&v)[MAXN], int n,
             const float d2 = diff * diff;
             acc += (double)d2;
         }
-    const float sd = (float)sqrt(acc / (double)n);
+    const float sd = (float)sqrt(div_by(acc, (double)n, yn));
     const double thr = (double)mean + coeff * (double)sd;
+    // (double)b <= thr for a byte b  <=>  b <= T  (a NaN threshold admits nothing, as in the reference)
+    const int T = thr >= 0.0 ? (int)fmin(thr, 255.0) : -1;
     int Si = 0, c = 0;
 #pragma unroll
     for (int k = 0; k < MAXN; ++k)
         if (FULL || k < n) {
             const int b = (v[k] >> (8 * j)) & 0xff;
-            if ((double)b <= thr) { Si += b; ++c; }
+            if (b <= T) { Si += b; ++c; }
         }
-    return c > 0 ? (float)Si / (float)c : mean;
+    return c > 0 ? (float)((double)Si * rcp[c]) : mean;
 }
 
 __device__ __forceinline__ float damage_threshold_f32(float bg)
 {
-    float t = bg / 255.0f;        // three separately rounded f32 ops, ip.py:638
+    float t = (float)((double)bg * (1.0 / 255.0));   // == bg / 255.0f; three separately rounded f32 ops, ip.py:638
     t = t * 225.0f;
     t = 30.0f + t;
     return fmaxf(30.0f, t);
@@ -102,6 +120,7 @@ __global__ __launch_bounds__(256) void detect_kernel(DetectArgs a)
     __shared__ __attribute__((aligned(16))) uint16_t s_hs[WIN_H * HS_STRIDE];   // later: flag bytes
     __shared__ __attribute__((aligned(16))) int32_t s_vs[TH * TW];
     __shared__ unsigned int s_cnt[2];
+    __shared__ double s_rcp[MAXN + 1];
 
     const int tid = threadIdx.x;
     const int H = a.H, W = a.W;
@@ -120,6 +139,7 @@ __global__ __launch_bounds__(256) void detect_kernel(DetectArgs a)
         return;
     }
     if (tid < 2) s_cnt[tid] = 0;
+    if (tid <= MAXN) s_rcp[tid] = tid ? 1.0 / (double)tid : 0.0;
 
     const uint8_t *frame = a.frames + (size_t)fi * H * W;
     const bool aligned = (W & 3) == 0;
@@ -210,7 +230,7 @@ __global__ __launch_bounds__(256) void detect_kernel(DetectArgs a)
             for (int j = 0; j < 4; ++j) {
                 if (gx + j < W) {
                     const int pix = (cen >> (8 * j)) & 0xff;
-                    const float bg = full ? background_px<MAXN, true>(v, nn, j, a.coeff) : background_px<MAXN, false>(v, nn, j, a.coeff);
+                    const float bg = full ? background_px<MAXN, true>(v, nn, j, a.coeff, s_rcp) : background_px<MAXN, false>(v, nn, j, a.coeff, s_rcp);
                     if (a.bg_out) a.bg_out[(size_t)gy * W + gx + j] = bg;
                     const float thr = damage_threshold_f32(bg);
                     const bool dmg = ((float)pix > thr) && (900 * pix > vs[j]);

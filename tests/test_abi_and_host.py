@@ -126,3 +126,20 @@ _Zgood:
 """
     assert [b[0] for b in mod.check_asm(sample)] == ["_Zbad"]
     assert mod.check_library() == []
+
+
+def test_f32_quotients_via_f64_reciprocal_are_exact():
+    """csrc/detect.hip replaces the f32 divisions S/n, Si/c and bg/255 by RN32(f64(a) * RN64(1/b)):
+    every S/n and Si/c a window of up to 16 neighbours can produce, and bg/255 over those quotients
+    plus a random sample of floats in [0, 256)."""
+    quot = []
+    for n in range(1, 17):
+        a = np.arange(0, 255 * n + 1)
+        ieee = a.astype(np.float32) / np.float32(n)
+        fast = (a.astype(np.float64) * (1.0 / n)).astype(np.float32)
+        assert np.array_equal(ieee, fast), n
+        quot.append(ieee)
+    rng = np.random.default_rng(5)
+    bg = np.concatenate(quot + [rng.uniform(0, 256, 2_000_000).astype(np.float32),
+                                np.ldexp(rng.integers(1, 1 << 24, 500_000).astype(np.float32), -16)])
+    assert np.array_equal(bg / np.float32(255.0), (bg.astype(np.float64) * (1.0 / 255.0)).astype(np.float32))
