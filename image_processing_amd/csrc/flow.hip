@@ -920,6 +920,11 @@ __global__ void first_frame_kernel(float *flows, uint8_t *keep)
 int build_plan(ipx_ctx *ctx, int H, int W)
 {
     if (ctx->flow_plan && ctx->flow_plan->H == H && ctx->flow_plan->W == W) return IPX_OK;
+    // flow_iter_kernel addresses the two expansions of a pair (40 bytes per pixel) with 32-bit buffer offsets
+    if ((size_t)H * W > ((size_t)1 << 26)) {
+        ipx_set_error("optical flow: frames of more than 2^26 pixels are not supported (got %d x %d)", H, W);
+        return IPX_ERR_UNSUPPORTED;
+    }
     IPX_CHECK_HIP(hipStreamSynchronize(ctx->stream));       // tables of the old plan may be in use
     ipx_flow_plan_free(ctx->flow_plan);
     ctx->flow_plan = nullptr;

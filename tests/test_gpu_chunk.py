@@ -64,6 +64,14 @@ def test_farneback_rejects_non_u8_images(eng):
         eng.farneback_pair(eng.to_device(a), eng.to_device(a))
 
 
+def test_flow_rejects_frames_beyond_32bit_addressing(eng):
+    import torch
+    from image_processing_amd._ipx import IpxError
+    big = torch.zeros((2, 8200, 8200), dtype=torch.uint8, device="cuda:0")      # > 2^26 pixels
+    with pytest.raises(IpxError, match="2\\^26"):
+        eng.flow_metric(big)
+
+
 def test_flow_metric_known_answers(eng):           # t.py:706-727
     z = np.zeros((3, 8, 8), np.uint8)
     flows, keep = eng.flow_metric(eng.to_device(z))
