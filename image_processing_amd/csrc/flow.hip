@@ -687,18 +687,32 @@ __global__ __launch_bounds__(FI_THREADS, 4) void flow_iter_kernel(const FiArgs a
         uedge = usx >= a.sw - 1;
         usx = max(0, min(usx, a.sw - 2));
     }
-    auto vec_issue = [&](int row) {
+    // The row tables of the upsampling are read one step before the flow loads that need them (row_tab, then
+    // vec_issue_t), and as scalar loads: because the kernel also writes memory the compiler would otherwise
+    // read them with vector loads, and a wave that waits for one of those cannot queue its next loads.
+    struct FiRow { int row, o0, o1; float b1; };
+    typedef const int __attribute__((address_space(4))) *fi_ctab_i;      // read-only for the whole launch:
+    typedef const float __attribute__((address_space(4))) *fi_ctab_f;    // constant address space = scalar loads
+    const fi_ctab_i c_yofs = (fi_ctab_i)(uintptr_t)a.y_ofs;
+    const fi_ctab_f c_yb = (fi_ctab_f)(uintptr_t)a.y_b;
+    auto row_tab = [&](int row) {
+        FiRow t; t.row = row; t.o0 = t.o1 = 0; t.b1 = 0.f;
+        if (IN == 2) { t.o0 = c_yofs[2 * row]; t.o1 = c_yofs[2 * row + 1]; t.b1 = c_yb[row]; }
+        return t;
+    };
+    auto vec_issue_t = [&](const FiRow &t) {
         FiVec v;
         if (IN == 0) {
-            v.p00 = fin[(size_t)row * w + ax];
+            v.p00 = fin[(size_t)t.row * w + ax];
         } else if (IN == 2) {
-            const float2 *S0 = fin + (size_t)a.y_ofs[2 * row] * a.sw, *S1 = fin + (size_t)a.y_ofs[2 * row + 1] * a.sw;
-            v.b1 = a.y_b[row];
+            const float2 *S0 = fin + (size_t)t.o0 * a.sw, *S1 = fin + (size_t)t.o1 * a.sw;
+            v.b1 = t.b1;
             const FiTaps t0 = *reinterpret_cast<const FiTaps *>(S0 + usx), t1 = *reinterpret_cast<const FiTaps *>(S1 + usx);
             v.p00 = t0.l; v.p01 = t0.r; v.p10 = t1.l; v.p11 = t1.r;
         }
         return v;
     };
+    auto vec_issue = [&](int row) { return vec_issue_t(row_tab(row)); };
     auto vec_finish = [&](const FiVec &v) {
         if (IN == 0) return v.p00;
         if (IN == 1) return make_float2(0.f, 0.f);
@@ -795,6 +809,7 @@ __global__ __launch_bounds__(FI_THREADS, 4) void flow_iter_kernel(const FiArgs a
         // memory pipe always has this wave's requests queued.
         UmIn in0, in1;
         float2 d0 = vec_finish(dv0), d1 = vec_finish(dv1);
+        FiRow tb0, tb1;
         {
             const int j0 = ys + FI_M + FI_G + prow, j1 = j0 + 2;     // rows of step 1
             const bool more = ys + FI_G < ye;
@@ -802,6 +817,8 @@ __global__ __launch_bounds__(FI_THREADS, 4) void flow_iter_kernel(const FiArgs a
             um_load(rR, FS, P16, d1, ax, clamp_row(j1), h, w, in1, more && col_used);
             dv0 = vec_issue(clamp_row(j0 + FI_G));
             dv1 = vec_issue(clamp_row(j1 + FI_G));
+            tb0 = row_tab(clamp_row(j0 + 2 * FI_G));
+            tb1 = row_tab(clamp_row(j1 + 2 * FI_G));
         }
 #pragma unroll 1
         for (int yb = ys; yb < ye; yb += FI_G) {
@@ -814,14 +831,16 @@ __global__ __launch_bounds__(FI_THREADS, 4) void flow_iter_kernel(const FiArgs a
             FI_STAMP(0);
             d0 = vec_finish(dv0);
             um_load(rR, FS, P16, d0, ax, clamp_row(j0 + FI_G), h, w, in0, more2 && col_used);
-            dv0 = vec_issue(clamp_row(j0 + 2 * FI_G));
+            dv0 = vec_issue_t(tb0);
+            tb0 = row_tab(clamp_row(j0 + 3 * FI_G));
             FI_STAMP(1);
             um_finish(in1, d1, ax, clamp_row(j1), h, w, m);
             if (more) ring_store(j1, m);
             FI_STAMP(2);
             d1 = vec_finish(dv1);
             um_load(rR, FS, P16, d1, ax, clamp_row(j1 + FI_G), h, w, in1, more2 && col_used);
-            dv1 = vec_issue(clamp_row(j1 + 2 * FI_G));
+            dv1 = vec_issue_t(tb1);
+            tb1 = row_tab(clamp_row(j1 + 3 * FI_G));
             FI_STAMP(3);
             fi_barrier();                                // ring rows of the next step written
             FI_STAMP(4);
