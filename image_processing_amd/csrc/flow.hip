@@ -714,7 +714,14 @@ __global__ __launch_bounds__(FI_THREADS, 4) void flow_iter_kernel(const FiArgs a
     };
     auto vec_issue = [&](int row) { return vec_issue_t(row_tab(row)); };
     auto vec_finish = [&](const FiVec &v) {
-        if (IN == 0) return v.p00;
+        if (IN == 0) {
+            // An opaque copy: the loaded vector's register is free again here, in the middle of a step, so the
+            // next load can target it.  Without it the value stays live into the step after next, the registers
+            // rotate at the loop's end, and that copy waits for every load the wave has in flight.
+            float2 o;
+            asm("v_mov_b32 %0, %2\n\tv_mov_b32 %1, %3" : "=&v"(o.x), "=&v"(o.y) : "v"(v.p00.x), "v"(v.p00.y));
+            return o;
+        }
         if (IN == 1) return make_float2(0.f, 0.f);
         float2 h0 = v.p01, h1 = v.p11, o;
         if (!uedge) {
@@ -820,6 +827,10 @@ __global__ __launch_bounds__(FI_THREADS, 4) void flow_iter_kernel(const FiArgs a
             tb0 = row_tab(clamp_row(j0 + 2 * FI_G));
             tb1 = row_tab(clamp_row(j1 + 2 * FI_G));
         }
+        // s_waitcnt vmcnt(0).  The compiler issues the loads above in an order of its own, and the counts it
+        // then waits for inside the loop are the worst case over both ways into it: without an empty queue
+        // here every step would begin by waiting for all of the wave's loads, the row in flight included.
+        __builtin_amdgcn_s_waitcnt(0x0F70);
 #pragma unroll 1
         for (int yb = ys; yb < ye; yb += FI_G) {
             const bool more = yb + FI_G < ye;            // the next step needs matrix rows yb+11 .. yb+14 (in flight)
