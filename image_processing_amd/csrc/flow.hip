@@ -577,10 +577,10 @@ __device__ __forceinline__ void um_finish(const UmIn &in, float2 d, int x, int y
 // 114 output columns (128 matrix columns with the window halo) and MARCHES down a segment of rows, 4 rows
 // per step, through a 23-row LDS ring of matrix rows.  The waves are specialised so that the memory phase
 // of one step runs under the arithmetic of the previous one:
-//   producers (waves 4-7): issue the expansion loads of the NEXT step's 4 matrix rows (two rows per
-//      thread), take part in B while they are in flight, and finish / store them into the ring during C;
-//   B  (all waves) threads own (column, channel) items and keep the running vertical 15-row sum in an f64
-//      register (+ new row - row leaving the window), writing the 4 rows of sums to LDS;
+//   producers (waves 4-7): two matrix rows per thread, row-pipelined: while one row is finished and stored
+//      into the ring, the loads of the other and of the row that replaces the finished one are in flight;
+//   B  (waves 0-3) threads own (column, channel group) items and keep the running vertical 15-row sums in f64
+//      registers (+ new row - row leaving the window), writing the 4 rows of sums to LDS;
 //   C  (waves 0-3, one row each) horizontal 15-sums slide over two adjacent outputs per thread, then the
 //      2x2 solve and the store (or the magnitude sum).
 // One workgroup barrier per step (plus an LDS counter on which the four consumer waves meet between B and C);
@@ -591,9 +591,14 @@ __device__ __forceinline__ void um_finish(const UmIn &in, float2 d, int x, int y
 // producers spend all of it blocked on the vector memory pipe (issue or data): the CU fetches ~25 KB of L1
 // misses per workgroup step, i.e. ~9 B/cycle/CU, which is what one CU gets from the fabric (~46 requests
 // outstanding at ~480 cycles each).  HBM itself is far from busy (halving the L2 misses with the XCD-aware
-// order changed nothing), and so are VALU (45 %) and LDS (46 %).  What moved the time: fewer L1 line requests
-// per pixel (float4 expansion planes: 8 loads instead of 15), keeping requests queued at all times (row
-// pipeline), taking B and the B->C hand-off off the producers.  What did not: replacing the barrier by
+// order changed nothing), and so are VALU (45 %) and LDS (46 %).  A level-0 launch runs at the rate of a
+// device-to-device copy (~4.9 TB/s algorithmic); the small levels (3 strips for 240 columns, short segments)
+// pull the average down.  What moved the time: fewer L1 line requests per pixel (float4 expansion planes:
+// 8 loads instead of 15), keeping requests queued at all times (row pipeline), taking B and the B->C hand-off
+// off the producers, and nothing in the producers' loop that waits for a load it does not need: the loop
+// must not begin with loads in flight that the compiler ordered differently from the loop's own (its wait
+// counts are the worst case over both entries), no loaded value may be copied at the loop's end, and tables
+// that are uniform per wave must be scalar loads (see row_tab).  What did not: replacing the barrier by
 // counters so that the producers run ahead (5.7k: the memory pipe, not the waiting, sets their pace), deeper
 // prefetch, 64-column strips, one output per thread in C, and 1024-thread workgroups whose two halves take
 // consecutive pairs in lockstep so that the shared expansion is fetched once per CU (the half that benefits
