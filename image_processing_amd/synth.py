@@ -73,6 +73,9 @@ def chunk_torch(seed, n, h, w, device, hot_per_mpix=490.0, stuck=20, speeds=None
         x = xx[None] - o
         y = yy[None]
         img = 70 + 35 * torch.sin(x / 97.0) * torch.cos(y / 71.0) + 15 * torch.sin((x + y) / 23.0)
+        if speeds:                                               # texture fine enough for the flow to lock on to
+            for kx, ky, ph in ((0.61, 0.23, 0.3), (0.17, 0.55, 1.1), (-0.41, 0.37, 2.0), (0.29, -0.47, 0.7), (0.83, 0.11, 2.9), (0.07, 0.31, 1.7)):
+                img = img + 9 * torch.sin(x * kx + y * ky + ph)
         img = img + 2.0 * torch.randn((nb, h, w), generator=g, device=device)
         by, bx = h // 2, w // 3
         img[:, by:by + 40, bx:bx + 40] = 200.0

@@ -81,6 +81,26 @@ def test_config3_camera_motion_heavy(eng):
     assert set(dropped) == {4, 9, 10, 11, 20, 30, 31, 40}
 
 
+def test_config3_1080p_known_translations(eng):
+    """The bench's --motion workload at full size (size-independent property: ground truth).  The scene moves
+    by 0, 0.5, 4 and 8 px/frame in 50-frame runs: the flow metric must recover those speeds (2 %), the runs
+    faster than flow_threshold = 2 are discarded, and discarded frames report NaN counts / zero clusters."""
+    import torch
+    from image_processing_amd import synth
+    fr = synth.chunk_torch(7, 200, 1080, 1920, torch.device("cuda", 0), speeds=[0, 0.5, 4, 8])
+    r = eng.detect_chunk(fr)
+    flows, keep = np.asarray(r["flows"]), np.asarray(r["keep"]).astype(bool)
+    for seg, v in enumerate([0.0, 0.5, 4.0, 8.0]):
+        f = flows[50 * seg + 1:50 * seg + 50] if seg == 0 else flows[50 * seg:50 * seg + 50]
+        if v == 0.0:
+            assert f.max() < 0.1                      # sensor noise only
+        else:
+            assert np.all(np.abs(f - v) <= 0.02 * v), (v, f.min(), f.max())
+    assert keep[:100].all() and not keep[100:].any()
+    assert np.isnan(r["total_counts"][100:]).all() and np.isfinite(r["total_counts"][:100]).all()
+    assert np.all(np.asarray(r["cluster_counts"])[100:] == 0)
+
+
 def test_config1_full_chunk_properties(eng):
     """1000 frames of 1080p (the bench workload): bitwise determinism, sharded == whole, and the flow metric
     of a sub-range equals the same frames' metric inside the whole chunk (pairs are independent)."""
