@@ -213,3 +213,10 @@ def test_farneback_restatement_recovers_a_known_translation(shift):
     assert abs(float(np.mean(mag[inner])) - shift) <= 0.03 * shift
     assert abs(float(np.mean(flow[inner][..., 0])) - shift) <= 0.03 * shift
     assert abs(float(np.mean(flow[inner][..., 1]))) <= 0.03 * shift
+
+
+def test_luma_known_answers():
+    """cvtColor(BGR2GRAY) on 8-bit input (ip.py:78-79; parity unpinned by the reference's tests): the values
+    OpenCV is known to give for the primaries and grey levels -- blue 29, green 150, red 76, grey g -> g."""
+    px = np.array([[[255, 0, 0], [0, 255, 0], [0, 0, 255], [255, 255, 255], [0, 0, 0], [128, 128, 128], [17, 17, 17]]], np.uint8)
+    assert cref.bgr2gray_u8(px).tolist() == [[29, 150, 76, 255, 0, 128, 17]]
