@@ -24,16 +24,20 @@ def _list(kind, payload):
 
 
 def write_avi(filename, frames, fps=25.0):
-    """frames: iterable of (H,W) uint8 (grey) or (H,W,3) uint8 (BGR) arrays, all of one shape."""
-    frames = [np.ascontiguousarray(f, dtype=np.uint8) for f in frames]
-    if not frames:
+    """frames: sequence of (H,W) uint8 (grey) or (H,W,3) uint8 (BGR) arrays, all of one shape.  Streams to
+    the file frame by frame (sizes are known up front), so a chunk is never held twice in memory."""
+    frames = frames if hasattr(frames, "__len__") else list(frames)
+    n = len(frames)
+    if not n:
         raise ValueError("no frames")
-    h, w = frames[0].shape[:2]
-    colour = frames[0].ndim == 3
+    first = np.asarray(frames[0])
+    h, w = first.shape[:2]
+    colour = first.ndim == 3
     bpp = 24 if colour else 8
     stride = (w * (3 if colour else 1) + 3) & ~3
     img_bytes = stride * h
-    n = len(frames)
+    if n * (img_bytes + 24) + 8192 > 0xFFFFFFFF:
+        raise ValueError("%d frames of %dx%d do not fit the 4 GB of a RIFF AVI; write several files" % (n, w, h))
     usec = int(round(1e6 / fps))
     rate, scale = int(round(fps * 1000)), 1000
     avih = struct.pack("<14I", usec, img_bytes * int(round(fps)), 0, 0x10, n, 0, 1, img_bytes, w, h, 0, 0, 0, 0)
@@ -43,21 +47,26 @@ def write_avi(filename, frames, fps=25.0):
     bih = struct.pack("<IiiHHIIiiII", 40, w, h, 1, bpp, 0, img_bytes, 0, 0, ncol, 0)
     pal = b"" if colour else b"".join(struct.pack("<4B", i, i, i, 0) for i in range(256))
     hdrl = _list(b"hdrl", _chunk(b"avih", avih) + _list(b"strl", _chunk(b"strh", strh) + _chunk(b"strf", bih + pal)))
-    movi_parts, index, off = [], [], 4
+    rec = 8 + img_bytes + (img_bytes & 1)                   # one '00db' chunk
+    movi_len = 4 + n * rec
+    idx_len = 16 * n
+    riff_len = 4 + len(hdrl) + (8 + movi_len) + (8 + idx_len)
     row = np.zeros((h, stride), np.uint8)
-    for f in frames:
-        if f.shape[:2] != (h, w) or (f.ndim == 3) != colour:
-            raise ValueError("all frames must have one shape")
-        row[:, :w * (3 if colour else 1)] = f.reshape(h, -1)
-        data = row[::-1].tobytes()                          # DIB rows are stored bottom-up
-        movi_parts.append(_chunk(b"00db", data))
-        index.append(struct.pack("<4sIII", b"00db", 0x10, off, len(data)))
-        off += 8 + len(data) + (len(data) & 1)
-    movi = _list(b"movi", b"".join(movi_parts))
-    idx1 = _chunk(b"idx1", b"".join(index))
-    body = b"AVI " + hdrl + movi + idx1
     with open(filename, "wb") as fh:
-        fh.write(b"RIFF" + struct.pack("<I", len(body)) + body)
+        fh.write(b"RIFF" + struct.pack("<I", riff_len) + b"AVI " + hdrl)
+        fh.write(b"LIST" + struct.pack("<I", movi_len) + b"movi")
+        head = b"00db" + struct.pack("<I", img_bytes)
+        for f in frames:
+            f = np.asarray(f)
+            if f.shape[:2] != (h, w) or (f.ndim == 3) != colour or f.dtype != np.uint8:
+                raise ValueError("all frames must be uint8 arrays of one shape")
+            row[:, :w * (3 if colour else 1)] = f.reshape(h, -1)
+            fh.write(head)
+            fh.write(row[::-1].tobytes())                   # DIB rows are stored bottom-up
+            if img_bytes & 1:
+                fh.write(b"\0")
+        fh.write(b"idx1" + struct.pack("<I", idx_len))
+        fh.write(b"".join(struct.pack("<4sIII", b"00db", 0x10, 4 + i * rec, img_bytes) for i in range(n)))
     return filename
 
 
@@ -126,6 +135,18 @@ class AviReader:
         if self.bpp == 8:
             return np.ascontiguousarray(a[:, :w])
         return np.ascontiguousarray(a[:, :3 * w].reshape(h, w, 3))
+
+    def read_into(self, i, out):
+        """Frame i of an 8-bit stream straight into ``out`` ((H,W) uint8, e.g. a row of a pinned buffer):
+        one copy from the page cache, rows put the right way up on the way."""
+        if self.bpp != 8:
+            raise ValueError("read_into is for 8-bit streams")
+        off, ln = self._frames[i]
+        h, w = self.height, self.width
+        if ln < self._stride * h:
+            raise ValueError("frame %d is truncated" % i)
+        a = np.frombuffer(self._mm, dtype=np.uint8, count=self._stride * h, offset=off).reshape(h, self._stride)
+        np.copyto(out, (a[::-1] if self._bottom_up else a)[:, :w])
 
     def close(self):
         if self._mm is not None:

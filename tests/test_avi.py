@@ -67,3 +67,37 @@ def test_read_gray_returns_the_stored_frames(tmp_path):
     cap = avi.VideoCapture(fn)
     assert not cap.is_gray()
     cap.release()
+
+
+def test_chunk_loader_short_cut_equals_load_video_frames(tmp_path, monkeypatch):
+    """image_processing._load_chunk reads 8-bit AVIs straight into one buffer; the frames must be the ones
+    load_video_frames returns (padded rows, bottom-up storage, ranges past the end), and a caller that
+    replaces load_video_frames gets theirs."""
+    import image_processing as ip
+    rng = np.random.default_rng(3)
+    fr = rng.integers(0, 256, (23, 37, 50), dtype=np.uint8)          # 50 columns: rows padded to 52 bytes
+    fn = str(tmp_path / "g.avi")
+    avi.write_avi(fn, fr)
+    for start, end in ((0, 10), (5, 23), (20, 1000)):
+        frames, _ = ip._load_chunk(fn, start, end)
+        ref = ip.load_video_frames(fn, frames_start=start, frames_end=end)
+        assert len(frames) == len(ref) == min(end, 23) - start
+        assert all(np.array_equal(a, b) for a, b in zip(frames, ref))
+        assert np.array_equal(frames[0], fr[start])
+    assert ip._load_chunk_gray_avi(fn, 0, 10) is not None
+    col = str(tmp_path / "c.avi")
+    avi.write_avi(col, rng.integers(0, 256, (4, 8, 8, 3), dtype=np.uint8))
+    assert ip._load_chunk_gray_avi(col, 0, 4) is None                  # colour: the general path
+    monkeypatch.setattr(ip, "load_video_frames", lambda *a, **k: [np.zeros((2, 2), np.uint8)] * 3)
+    assert ip._load_chunk_gray_avi(fn, 0, 10) is None
+    frames, _ = ip._load_chunk(fn, 0, 10)
+    assert len(frames) == 3 and frames[0].shape == (2, 2)
+
+
+def test_write_avi_refuses_more_than_4_gb():
+    class Fake(np.ndarray):
+        pass
+    big = np.zeros((1, 1), np.uint8)
+    frames = [np.broadcast_to(big, (4096, 4096))] * 300                 # 300 x 16 MB > 4 GB, no memory used
+    with pytest.raises(ValueError, match="4 GB"):
+        avi.write_avi("/nonexistent/never_written.avi", frames)

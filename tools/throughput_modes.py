@@ -48,8 +48,9 @@ def main():
           % (chunks * n / dt, chunks, n, chunks * n * H * W / dt / 1e9))
     fn = os.path.join("/tmp", "ipx_bench_%d.avi" % os.getpid())
     host = [p.numpy() for p in pinned]
+    n = min(n, int(3.9e9 / (H * W)) // chunks)            # a RIFF AVI holds 4 GB
     t0 = time.perf_counter()
-    avi.write_avi(fn, (host[c % 2][i] for c in range(chunks) for i in range(n)), fps=25.0)
+    avi.write_avi(fn, [host[c % 2][i] for c in range(chunks) for i in range(n)], fps=25.0)
     print("wrote %s: %.1f GB in %.1f s" % (fn, os.path.getsize(fn) / 1e9, time.perf_counter() - t0))
     try:
         t0 = time.perf_counter()
