@@ -11,10 +11,11 @@
 // with 11-tap separable filters, vertical pass in f32, horizontal pass in f64; matrix update with
 // a bilinear sample of the second expansion and border damping; 15x15 box window in f64 and a
 // regularised 2x2 solve).  Every per-pixel expression is evaluated with the same types and
-// operation order (no FMA contraction); two reductions are re-associated for parallelism and
-// stay inside the 1e-5 relative tolerance of the float metric: the 15x15 window (direct f64
-// sums instead of running sums) and the mean magnitude (f64 tree instead of numpy's f32
-// pairwise sum).
+// operation order (no FMA contraction), and so are the vertical running sums of the 15x15 window,
+// f32-rounded updates included.  Two reductions are formed in a different order: the window's
+// horizontal 15-sums (f64; a flow value can differ from the reference's by one f32 ulp, rarely --
+// none of the ~1e9 values of the parity tests does) and the mean magnitude (f64 tree instead of
+// numpy's f32 pairwise sum; inside the 1e-5 relative tolerance of the float metric).
 //
 // MI355X design: a batch of up to 256 consecutive pairs is processed per launch so that the coarse pyramid
 // levels still fill 256 CUs; the polynomial expansion of a frame is computed once and serves both pairs it
@@ -766,8 +767,18 @@ __global__ __launch_bounds__(FI_THREADS, 4) void flow_iter_kernel(const FiArgs a
     const int vi = (ac >> 1) + (ac & 1) * FI_HALF;
     double *vob = s_v + bch0 * (FI_G * FI_MC) + vi;
     double vs[3] = {0.0, 0.0, 0.0};
+    // The reference's vertical sum is a running sum from the top of the image whose every update is rounded
+    // to f32 first: vsum = f32(row0 * 9) + rows 1..6, then per row vsum += f32(row[y+7] - row[y-8]).  A segment
+    // that starts at row 0 repeats exactly that (run_pairs uses one segment per strip); a segment that starts
+    // further down would begin with the plain sum of its 15 rows, which differs in the last bits.
+    const bool from_top = ys == 0;
     if (!producer) {
-        for (int i = 1; i <= 2 * FI_M; ++i) {            // first output row: rows ys-7 .. ys+6 = slots 1 .. 14
+        if (from_top) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+                if (c < nbch) vs[c] = (double)(colb[8 * FI_MROW + c * FI_MC] * (float)(FI_M + 2));   // slot 8 = row 0
+        }
+        for (int i = from_top ? 9 : 1; i <= 2 * FI_M; ++i) {   // rows ys-7 .. ys+6 = slots 1 .. 14
 #pragma unroll
             for (int c = 0; c < 3; ++c)
                 if (c < nbch) vs[c] += (double)colb[i * FI_MROW + c * FI_MC];
@@ -788,11 +799,12 @@ __global__ __launch_bounds__(FI_THREADS, 4) void flow_iter_kernel(const FiArgs a
             if (first_step && r == 0) {
 #pragma unroll
                 for (int c = 0; c < 3; ++c)
-                    if (c < nbch) vs[c] += (double)pin[c * FI_MC];
+                    if (c < nbch) vs[c] += from_top ? (double)(pin[c * FI_MC] - colb[FI_MROW + c * FI_MC])   // row -8 = row 0 = slot 1
+                                                    : (double)pin[c * FI_MC];
             } else {
 #pragma unroll
                 for (int c = 0; c < 3; ++c)
-                    if (c < nbch) vs[c] += (double)pin[c * FI_MC] - (double)pout[c * FI_MC];
+                    if (c < nbch) vs[c] += (double)(pin[c * FI_MC] - pout[c * FI_MC]);
                 slot_out = slot_out + 1 == FI_RING ? 0 : slot_out + 1;
             }
             slot_in = slot_in + 1 == FI_RING ? 0 : slot_in + 1;
@@ -1120,13 +1132,12 @@ FiGeom fi_geometry(const LevelGeom &g, int np)
 {
     FiGeom f;
     f.strips = (g.lw + FI_TW - 1) / FI_TW;
-    int nseg = (4096 + f.strips * np - 1) / (f.strips * np);   // measured flat between 1536 and 4096 workgroups
-    const int max_seg = (g.lh + 63) / 64;
-    if (nseg > max_seg) nseg = max_seg;
-    if (nseg < 1) nseg = 1;
-    int seg_rows = (g.lh + nseg - 1) / nseg;
-    f.seg_rows = (seg_rows + FI_G - 1) / FI_G * FI_G;
-    f.nseg = (g.lh + f.seg_rows - 1) / f.seg_rows;
+    // One segment per strip: only a march that starts at row 0 reproduces the reference's running vertical
+    // sums bit for bit (flow_iter_kernel).  The kernel itself can cut a strip into several segments; that was
+    // measured to change nothing for the 256-pair batches of a chunk (1024 to 8192 workgroups per launch).
+    (void)np;
+    f.nseg = 1;
+    f.seg_rows = (g.lh + FI_G - 1) / FI_G * FI_G;
     f.ppx = (np + 7) / 8;                                   // pairs per XCD
     return f;
 }

@@ -2,9 +2,11 @@
 the golden outputs of the reference's own orchestration.  Needs an MI355X: ``-m gpu``.
 
 Tolerances (north_star: bit-exact masks / discard lists / counts, 1e-5 relative float metrics):
-* flow field: per-pixel expressions are evaluated exactly as the oracle does; the 15x15 window
-  sums and the mean are re-associated (csrc/flow.hip), so fields agree to ~1e-5 absolute and the
-  mean magnitude to 1e-5 relative;
+* flow field: per-pixel expressions, the vertical 15-row running sums (including their f32-rounded updates) and
+  the solve are evaluated exactly as the oracle does; only the horizontal 15-sums are formed in a different
+  order, in f64, so a field value can differ from the oracle's by one f32 ulp at most, and rarely: the test
+  allows 1e-5 of the values to differ, by no more than 1e-6 of the flow scale (measured: none differ);
+* the mean magnitude is an f64 tree against numpy's f32 pairwise sum: 1e-5 relative;
 * everything downstream of the discard list is compared bit-exactly.
 """
 import numpy as np
@@ -41,7 +43,7 @@ def _moving_pair(seed, h, w, shift):
 
 # (h, w): single level; 3 exact halvings; odd sizes (general linear resize); non-multiple-of-64 widths
 @pytest.mark.parametrize("shape,shift", [((40, 56), 1.0), ((264, 360), 3.0), ((131, 203), 0.7), ((270, 480), 6.0),
-                                         ((67, 300), 2.0)])
+                                         ((67, 300), 2.0), ((540, 960), 4.0)])
 def test_farneback_pair_field(eng, shape, shift):
     from oracle import cref
     h, w = shape
@@ -51,7 +53,8 @@ def test_farneback_pair_field(eng, shape, shift):
     assert got.shape == ref.shape and np.isfinite(got).all()
     err = np.abs(got.astype(np.float64) - ref.astype(np.float64))
     scale = max(1.0, float(np.abs(ref).max()))
-    assert err.max() <= 2e-4 * scale, "max |dflow| = %g (flow scale %g)" % (err.max(), scale)
+    assert err.max() <= 1e-6 * scale, "max |dflow| = %g (flow scale %g)" % (err.max(), scale)
+    assert int((err > 0).sum()) <= 1e-5 * err.size, "%d of %d flow values differ" % (int((err > 0).sum()), err.size)
     mref = float(np.mean(cref.flow_magnitude(ref)))
     mgot = float(np.mean(cref.flow_magnitude(got)))
     assert abs(mgot - mref) <= FLOW_RTOL * max(mref, 1e-30)
@@ -178,3 +181,17 @@ def test_async_chunks_overlap_and_match(eng):
         for k in ("total_counts", "cluster_counts", "avg_sizes", "avg_brightnesses", "flows"):
             assert _eq_nan(got[k], ref[k]), k
         assert np.array_equal(got["keep"], ref["keep"]) and np.array_equal(got["counts"], ref["counts"])
+
+
+def test_randomised_parity_sweep(eng):
+    """tools/fuzz_parity.py: random sizes (odd ones included), chunk lengths, parameter sets and scenes, the
+    whole path against the oracle, bit-exact downstream of the flow metric."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tools"))
+    import fuzz_parity
+    done = 0
+    for seed in range(7000, 7150):
+        msg = fuzz_parity.one_case(eng, seed)
+        done += msg.startswith("ok")
+    assert done >= 140

@@ -1,7 +1,7 @@
 """HIP stages (through the C ABI of include/ipx.h) vs the CPU oracle, stage by stage.
 
 Bit-exact for masks, planes, counters and the f32 background; the Farneback flow field is
-compared with a stated tolerance (two reductions are re-associated on the GPU, csrc/flow.hip).
+compared with a stated tolerance (two reductions are formed in a different order on the GPU, csrc/flow.hip).
 Needs an MI355X: run with ``-m gpu``.
 """
 import numpy as np

@@ -1,0 +1,81 @@
+#!/usr/bin/env python3
+"""Randomised parity sweep of the whole path against the CPU oracle (a checker, like tests/): random frame
+sizes (odd ones included), chunk lengths, parameter sets and scene contents.  Run on the GPU box:
+    python tools/fuzz_parity.py [cases] [seed]
+Prints one line per case and exits non-zero at the first mismatch (the case's seed reproduces it)."""
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+FLOW_RTOL = 1e-5
+
+
+def eq_nan(a, b):
+    return np.array_equal(np.asarray(a, float), np.asarray(b, float), equal_nan=True)
+
+
+def one_case(eng, seed):
+    from image_processing_amd import synth
+    from oracle import pipeline
+    rng = np.random.default_rng(seed)
+    h = int(rng.integers(34, 200)); w = int(rng.integers(34, 260)); n = int(rng.integers(2, 40))
+    params = dict(consecutive_threshold=int(rng.integers(1, 5)), brightness_threshold=int(rng.integers(120, 220)),
+                  flow_threshold=float(rng.choice([0.05, 0.5, 2.0, 4.0])), static_threshold=float(rng.choice([5, 20, 50])),
+                  min_cluster_size=int(rng.integers(1, 4)), max_cluster_size=int(rng.integers(6, 40)),
+                  min_circularity=float(rng.choice([0.0, 0.3, 0.6])), sliding_window_radius=int(rng.integers(1, 6)))
+    motion = tuple(int(x) for x in rng.choice(np.arange(1, max(2, n)), size=min(int(rng.integers(0, 4)), max(1, n - 1)), replace=False)) if n > 2 else ()
+    frames = synth.chunk_numpy(seed, n, h, w, hot=float(rng.uniform(2, 30)), stuck=int(rng.integers(0, 6)),
+                               bright_block=bool(rng.integers(0, 2)), motion_at=motion, shift=float(rng.uniform(0.5, 9)),
+                               blobs=int(rng.integers(0, 6)))
+    (total, cc, sz, br), mid = pipeline.detect_damaged_pixels(frames, params=params, return_intermediates=True)
+    eng.set_params(params)
+    try:
+        r = eng.detect_chunk(frames, want_masks=True)
+    finally:
+        eng.set_params(None)
+    thr = params["flow_threshold"]
+    near = np.abs(mid["flows"] - thr) <= 1e-4 * thr
+    if near.any():
+        return "skipped (a flow metric within 1e-4 of the threshold)"
+    if not np.allclose(r["flows"], mid["flows"], rtol=FLOW_RTOL, atol=1e-12):
+        got, ref = np.asarray(r["flows"], float), np.asarray(mid["flows"], float)
+        rel = np.abs(got - ref) / np.maximum(np.abs(ref), 1e-30)
+        i = int(np.argmax(rel))
+        raise AssertionError("flows: %dx%d n=%d frame %d got %.9g ref %.9g rel %.3g (motion_at=%s)" % (w, h, n, i, got[i], ref[i], rel[i], motion))
+    assert np.array_equal(r["keep"].astype(bool), mid["flows"] <= thr), "keep"
+    for i in range(n):
+        if mid["final"][i] is None:
+            assert r["final_masks"][i] is None, "final mask %d should be None" % i
+        else:
+            assert np.array_equal(r["final_masks"][i], mid["final"][i]), "final mask %d" % i
+    assert eq_nan(r["total_counts"], total), "total counts"
+    assert eq_nan(r["cluster_counts"], cc) and eq_nan(r["avg_sizes"], sz) and eq_nan(r["avg_brightnesses"], br), "cluster stats"
+    return "ok  %3dx%-3d n=%-2d kept=%-2d counts=%d clusters=%d r=%d T=%d" % (
+        w, h, n, int(np.sum(r["keep"])), int(np.nansum(total)), int(np.nansum(cc)), params["sliding_window_radius"],
+        params["consecutive_threshold"])
+
+
+def main():
+    from image_processing_amd.engine import Engine
+    cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+    seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
+    eng = Engine(0)
+    t0 = time.time()
+    for k in range(cases):
+        seed = seed0 + k
+        try:
+            msg = one_case(eng, seed)
+        except AssertionError as e:
+            print("seed %d: MISMATCH %s" % (seed, e), flush=True)
+            sys.exit(1)
+        print("seed %d: %s  [%.0f s]" % (seed, msg, time.time() - t0), flush=True)
+    eng.close()
+    print("%d cases passed" % cases)
+
+
+if __name__ == "__main__":
+    main()
