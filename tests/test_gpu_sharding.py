@@ -94,3 +94,20 @@ def test_sharded_threads_equal_whole_chunk(world, n, params):
             exp = ref["final_masks"][i]
             assert np.array_equal(res["final"][i - a], np.zeros((h, w), bool) if exp is None else exp)
     assert np.isnan(ref["total_counts"]).any() and np.nansum(ref["total_counts"]) > 0
+
+
+def test_randomised_sharding_sweep():
+    """tools/fuzz_sharded.py: random world sizes (2-4), chunk lengths down to the minimum a shard may hold,
+    parameter sets and runs of lit pixels across shard edges; sharded == whole chunk, bit for bit."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tools"))
+    import fuzz_sharded
+    from image_processing_amd.engine import Engine
+    engines = [Engine(0) for _ in range(5)]
+    try:
+        for seed in range(3000, 3080):
+            assert fuzz_sharded.one_case(engines, seed).startswith("ok")
+    finally:
+        for e in engines:
+            e.close()

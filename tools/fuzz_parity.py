@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Randomised parity sweep of the whole path against the CPU oracle (a checker, like tests/): random frame
 sizes (odd ones included), chunk lengths, parameter sets and scene contents.  Run on the GPU box:
-    python tools/fuzz_parity.py [cases] [seed]
+    python tools/fuzz_parity.py [cases] [seed] [max_side]
 Prints one line per case and exits non-zero at the first mismatch (the case's seed reproduces it)."""
 import os
 import sys
@@ -18,11 +18,11 @@ def eq_nan(a, b):
     return np.array_equal(np.asarray(a, float), np.asarray(b, float), equal_nan=True)
 
 
-def one_case(eng, seed):
+def one_case(eng, seed, max_side=260):
     from image_processing_amd import synth
     from oracle import pipeline
     rng = np.random.default_rng(seed)
-    h = int(rng.integers(34, 200)); w = int(rng.integers(34, 260)); n = int(rng.integers(2, 40))
+    h = int(rng.integers(34, max(35, int(max_side * 0.77)))); w = int(rng.integers(34, max_side)); n = int(rng.integers(2, 40))
     params = dict(consecutive_threshold=int(rng.integers(1, 5)), brightness_threshold=int(rng.integers(120, 220)),
                   flow_threshold=float(rng.choice([0.05, 0.5, 2.0, 4.0])), static_threshold=float(rng.choice([5, 20, 50])),
                   min_cluster_size=int(rng.integers(1, 4)), max_cluster_size=int(rng.integers(6, 40)),
@@ -63,12 +63,13 @@ def main():
     from image_processing_amd.engine import Engine
     cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
     seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
+    max_side = int(sys.argv[3]) if len(sys.argv) > 3 else 260
     eng = Engine(0)
     t0 = time.time()
     for k in range(cases):
         seed = seed0 + k
         try:
-            msg = one_case(eng, seed)
+            msg = one_case(eng, seed, max_side)
         except AssertionError as e:
             print("seed %d: MISMATCH %s" % (seed, e), flush=True)
             sys.exit(1)
