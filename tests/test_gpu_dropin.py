@@ -278,3 +278,15 @@ def test_main_checkpoints_and_resumes(ip, tmp_path, monkeypatch):
     assert loaded == [(10, 15)]
     for k in first:
         assert _eq_nan(first[k], again[k]), k
+
+
+def test_randomised_labelling_stages_sweep():
+    """tools/fuzz_stages.py: filter_damaged_pixel_clusters and remove_bright_regions of this module against
+    the oracle on random masks (noise of any density, lines, rings, solid and hollow shapes, border contact)."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tools"))
+    import fuzz_stages
+    import image_processing as ip
+    for seed in range(50000, 50200):
+        assert fuzz_stages.one_case(ip, seed).startswith("ok")

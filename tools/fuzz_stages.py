@@ -1,0 +1,101 @@
+#!/usr/bin/env python3
+"""Randomised parity of the two labelling stages through the drop-in module's own functions, on masks the
+whole-path sweep never produces (noise of any density, lines, rings, solid and hollow shapes, big clusters):
+    filter_damaged_pixel_clusters  (close + CCL + size filter + contour perimeter / circularity + means)
+    remove_bright_regions          (two CCLs + overlap rules)
+against oracle/stages.py, bit-exact masks and equal statistics.
+    python tools/fuzz_stages.py [cases] [seed]"""
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def random_mask(rng, h, w):
+    m = np.zeros((h, w), bool)
+    kind = int(rng.integers(0, 5))
+    if kind in (0, 4):
+        m |= rng.random((h, w)) < float(rng.choice([0.002, 0.01, 0.05, 0.2, 0.45, 0.7]))
+    if kind in (1, 4):
+        for _ in range(int(rng.integers(1, 25))):            # solid / hollow boxes and ellipses
+            cy, cx = int(rng.integers(0, h)), int(rng.integers(0, w))
+            ry, rx = int(rng.integers(1, 14)), int(rng.integers(1, 14))
+            yy, xx = np.ogrid[:h, :w]
+            if rng.random() < 0.5:
+                shape = (abs(yy - cy) <= ry) & (abs(xx - cx) <= rx)
+                inner = (abs(yy - cy) < ry - 1) & (abs(xx - cx) < rx - 1)
+            else:
+                shape = ((yy - cy) / ry) ** 2 + ((xx - cx) / rx) ** 2 <= 1.0
+                inner = ((yy - cy) / max(ry - 1.5, 0.5)) ** 2 + ((xx - cx) / max(rx - 1.5, 0.5)) ** 2 <= 1.0
+            m |= (shape & ~inner) if rng.random() < 0.4 else shape
+    if kind in (2, 4):
+        for _ in range(int(rng.integers(1, 20))):            # lines of every slope
+            y0, x0 = int(rng.integers(0, h)), int(rng.integers(0, w))
+            dy, dx = int(rng.integers(-12, 13)), int(rng.integers(-12, 13))
+            steps = max(abs(dy), abs(dx), 1)
+            for t in range(steps + 1):
+                y, x = y0 + round(dy * t / steps), x0 + round(dx * t / steps)
+                if 0 <= y < h and 0 <= x < w:
+                    m[y, x] = True
+    if kind == 3:
+        m |= rng.random((h, w)) < 0.03                       # noise, grown
+        g = m.copy()
+        g[1:] |= m[:-1]; g[:, 1:] |= m[:, :-1]
+        if rng.random() < 0.5:
+            g[:-1] |= m[1:]; g[:, :-1] |= m[:, 1:]
+        m = g
+    if rng.random() < 0.3:                                   # something on the border
+        m[0, :] |= rng.random(w) < 0.3; m[:, -1] |= rng.random(h) < 0.3
+    return m
+
+
+def one_case(ip, seed):
+    from oracle import stages as S
+    rng = np.random.default_rng(seed)
+    h, w = int(rng.integers(3, 150)), int(rng.integers(3, 200))
+    frame = rng.integers(0, 256, (h, w), dtype=np.uint8)
+    mask = random_mask(rng, h, w)
+    lo = int(rng.integers(1, 6)); hi = int(rng.choice([5, 20, 60, 400, 5000])); circ = float(rng.choice([0.0, 0.2, 0.5, 0.785, 0.9]))
+    cst = int(rng.choice([1, 4, 10, 10, 10, 25]))
+    ref = S.filter_damaged_pixel_clusters(frame, mask, lo, hi, circ, cst)
+    got = ip.filter_damaged_pixel_clusters(frame, mask, lo, hi, circ, cst)
+    assert np.array_equal(got[0], ref[0]), "cluster mask"
+    assert got[1] == ref[1], "cluster count %r vs %r" % (got[1], ref[1])
+    assert got[2] == ref[2], "mean area %r vs %r" % (got[2], ref[2])
+    assert (np.isnan(got[3]) and np.isnan(ref[3])) or got[3] == ref[3], "mean brightness %r vs %r" % (got[3], ref[3])
+    # remove_bright_regions: a smooth background with saturated patches, another random mask
+    bg = rng.uniform(0, 160, (h, w)).astype(np.float32)
+    for _ in range(int(rng.integers(0, 6))):
+        y, x = int(rng.integers(0, h)), int(rng.integers(0, w))
+        bg[y:y + int(rng.integers(1, 30)), x:x + int(rng.integers(1, 30))] = float(rng.uniform(150, 255))
+    dm = random_mask(rng, h, w)
+    bt = float(rng.choice([120, 170, 200])); mcs = int(rng.choice([3, 20, 80]))
+    r2 = S.remove_bright_regions(bg, bt, dm, mcs)
+    g2 = ip.remove_bright_regions(bg, bt, dm, mcs)
+    assert np.array_equal(np.asarray(g2, bool), np.asarray(r2, bool)), "remove_bright_regions"
+    return "ok  %3dx%-3d mask %5d px -> %3d clusters (size %d..%d, circ %.2f @%d); bright regions removed %d px" % (
+        w, h, int(mask.sum()), ref[1], lo, hi, circ, cst, int(dm.sum()) - int(np.asarray(r2, bool).sum()))
+
+
+def main():
+    import image_processing as ip
+    cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+    seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 100
+    t0 = time.time()
+    for k in range(cases):
+        try:
+            msg = one_case(ip, seed0 + k)
+        except AssertionError as e:
+            print("seed %d: MISMATCH %s" % (seed0 + k, e), flush=True)
+            sys.exit(1)
+        if k % 20 == 0 or k == cases - 1:
+            print("seed %d: %s  [%.0f s]" % (seed0 + k, msg, time.time() - t0), flush=True)
+    print("%d cases passed" % cases)
+
+
+if __name__ == "__main__":
+    main()
