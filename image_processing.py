@@ -207,11 +207,12 @@ def _find_background(frames, pixel_std_coeff=1.0):
     <= mean + coeff*std per pixel, float32."""
     stack = _as_u8(frames)
     n = len(stack)
-    if not 1 <= n <= 8:
-        raise ValueError("_find_background handles 1..8 neighbour frames on the GPU (window radius <= 8)")
-    ext = np.concatenate([stack, stack[:1]])            # dummy centre at index n; window = all n others
-    with _Scoped(sliding_window_radius=n, pixel_std_coeff=float(pixel_std_coeff)) as eng:
-        return eng.background(eng.to_device(ext), n).cpu().numpy()
+    if not 1 <= n <= 16:
+        raise ValueError("_find_background handles 1..16 neighbour frames on the GPU (window radius <= 8)")
+    k = n // 2                                          # dummy centre in the middle; window = all n others, in order
+    ext = np.concatenate([stack[:k], stack[:1], stack[k:]])
+    with _Scoped(sliding_window_radius=max(k, n - k), pixel_std_coeff=float(pixel_std_coeff)) as eng:
+        return eng.background(eng.to_device(ext), k).cpu().numpy()
 
 
 # ---------------------------------------------------------------------------------------------

@@ -3,7 +3,9 @@
 whole-path sweep never produces (noise of any density, lines, rings, solid and hollow shapes, big clusters):
     filter_damaged_pixel_clusters  (close + CCL + size filter + contour perimeter / circularity + means)
     remove_bright_regions          (two CCLs + overlap rules)
-against oracle/stages.py, bit-exact masks and equal statistics.
+and of compute_background / _find_background / get_damaged_pixel_mask on frames of any content (white noise,
+sparse extremes, constants; window radius 1..8), against oracle/stages.py: bit-exact masks and float32
+backgrounds / thresholds, equal statistics.
     python tools/fuzz_stages.py [cases] [seed]"""
 import os
 import sys
@@ -77,6 +79,31 @@ def one_case(ip, seed):
     r2 = S.remove_bright_regions(bg, bt, dm, mcs)
     g2 = ip.remove_bright_regions(bg, bt, dm, mcs)
     assert np.array_equal(np.asarray(g2, bool), np.asarray(r2, bool)), "remove_bright_regions"
+    # background + raw mask on frames of any content (the scenes of the whole-path sweep are smooth):
+    # white noise, sparse extremes, constants, +-1 jitter; window radius 1..8, several outlier coefficients
+    n = int(rng.integers(2, 20)); radius = int(rng.integers(1, 9))
+    hh, ww = int(rng.integers(1, 70)), int(rng.integers(1, 100))
+    kind = int(rng.integers(0, 4))
+    if kind == 0:
+        fr = rng.integers(0, 256, (n, hh, ww), dtype=np.uint8)
+    elif kind == 1:
+        fr = np.where(rng.random((n, hh, ww)) < 0.1, rng.choice([1, 254, 255], (n, hh, ww)), 0).astype(np.uint8)
+    elif kind == 2:
+        fr = np.full((n, hh, ww), int(rng.integers(0, 256)), np.uint8)
+    else:
+        fr = np.clip(int(rng.integers(0, 256)) + rng.integers(-1, 2, (n, hh, ww)), 0, 255).astype(np.uint8)
+    i = int(rng.integers(0, n))
+    b_ref = S.compute_background(fr, i, radius)
+    b_got = ip.compute_background(fr, i, radius)
+    assert b_got.dtype == np.float32 and np.array_equal(b_got, b_ref), "compute_background (radius %d, kind %d)" % (radius, kind)
+    idx = S.background_window(n, i, radius)
+    coeff = float(rng.choice([0.0, 0.5, 1.0, 2.0, -1.0]))
+    f_ref = S.compute_background(fr, i, radius, coeff)
+    f_got = ip._find_background(fr[idx].astype(np.float32), coeff)
+    assert np.array_equal(f_got, f_ref), "_find_background (coeff %g, %d neighbours)" % (coeff, len(idx))
+    m_ref, t_ref = S.get_damaged_pixel_mask(fr[i], b_ref)
+    m_got, t_got = ip.get_damaged_pixel_mask(fr[i], hh, ww, b_ref)
+    assert np.array_equal(m_got, m_ref) and np.array_equal(t_got, t_ref), "get_damaged_pixel_mask"
     return "ok  %3dx%-3d mask %5d px -> %3d clusters (size %d..%d, circ %.2f @%d); bright regions removed %d px" % (
         w, h, int(mask.sum()), ref[1], lo, hi, circ, cst, int(dm.sum()) - int(np.asarray(r2, bool).sum()))
 
