@@ -290,3 +290,4 @@ def test_randomised_labelling_stages_sweep():
     import image_processing as ip
     for seed in range(50000, 50200):
         assert fuzz_stages.one_case(ip, seed).startswith("ok")
+        assert fuzz_stages.temporal_case(ip, seed) == "ok"

@@ -5,7 +5,8 @@ whole-path sweep never produces (noise of any density, lines, rings, solid and h
     remove_bright_regions          (two CCLs + overlap rules)
 and of compute_background / _find_background / get_damaged_pixel_mask on frames of any content (white noise,
 sparse extremes, constants; window radius 1..8), against oracle/stages.py: bit-exact masks and float32
-backgrounds / thresholds, equal statistics.
+backgrounds / thresholds, equal statistics; and (temporal_case) of the temporal stages and estimates on
+arbitrary mask lists with None entries.
     python tools/fuzz_stages.py [cases] [seed]"""
 import os
 import sys
@@ -108,6 +109,50 @@ def one_case(ip, seed):
         w, h, int(mask.sum()), ref[1], lo, hi, circ, cst, int(dm.sum()) - int(np.asarray(r2, bool).sum()))
 
 
+def _same_list(got, ref):
+    assert len(got) == len(ref)
+    for g, r in zip(got, ref):
+        assert (g is None) == (r is None), "None pattern"
+        if r is not None:
+            assert np.array_equal(np.asarray(g, bool), np.asarray(r, bool)), "mask"
+
+
+def _same_f(got, ref, what):
+    assert np.array_equal(np.asarray(got, float), np.asarray(ref, float), equal_nan=True), what
+
+
+def temporal_case(ip, seed):
+    """The temporal stages on arbitrary mask lists (dense masks, None entries anywhere but frame 0)."""
+    from oracle import stages as S
+    rng = np.random.default_rng(seed)
+    n = int(rng.integers(1, 30)); h = int(rng.integers(1, 50)); w = int(rng.integers(1, 140))
+    frames = [rng.integers(0, 256, (h, w), dtype=np.uint8) for _ in range(n)]
+    dens = float(rng.choice([0.0, 0.02, 0.3, 0.6, 1.0]))
+    base = rng.random((h, w)) < dens                          # pixels that tend to stay lit: runs and static pixels
+    masks = [None if (i > 0 and rng.random() < 0.2) else ((rng.random((h, w)) < dens) | (base & (rng.random((h, w)) < 0.8)))
+             for i in range(n)]
+    T = int(rng.integers(0, 6))
+    p_ref = S.compute_persistent_mask(masks, T)
+    p_got = ip.compute_persistent_mask(masks, T)
+    assert np.array_equal(np.asarray(p_got, bool), p_ref), "compute_persistent_mask T=%d" % T
+    f_ref, c_ref = S.filter_consecutive_pixels(masks, p_ref)
+    f_got, c_got = ip.filter_consecutive_pixels(masks, p_ref)
+    _same_list(f_got, f_ref); _same_f(c_got, c_ref, "filter_consecutive_pixels counts")
+    bt = float(rng.choice([100, 170, 250])); st = float(rng.choice([0, 5, 20, 50, 99])); mv = int(rng.choice([0, 3, 10, 40]))
+    s_ref = S.compute_static_mask(frames, masks, bt, st, mv)
+    s_got = ip.compute_static_mask(frames, masks, bt, st, mv)
+    assert np.array_equal(np.asarray(s_got, bool), s_ref), "compute_static_mask"
+    a_ref, ac_ref = S.apply_static_suppression(masks, p_ref, s_ref)
+    a_got, ac_got = ip.apply_static_suppression(masks, p_ref, s_ref)
+    _same_list(a_got, a_ref); _same_f(ac_got, ac_ref, "apply_static_suppression counts")
+    thr = int(rng.choice([1, 170, 170, 200, 256]))
+    _same_f(ip.estimate_damaged_pixels_in_bright_areas(frames, a_ref, thr), S.estimate_damaged_pixels_in_bright_areas(frames, a_ref, thr), "estimates")
+    e_ref = S.find_bright_area_estimates(frames, a_ref, bt)
+    _same_f(ip.find_bright_area_estimates(frames, a_ref, bt), e_ref, "find_bright_area_estimates")
+    _same_f(ip._get_final_count(a_ref, e_ref), S.get_final_count(a_ref, e_ref), "_get_final_count")
+    return "ok"
+
+
 def main():
     import image_processing as ip
     cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
@@ -116,6 +161,7 @@ def main():
     for k in range(cases):
         try:
             msg = one_case(ip, seed0 + k)
+            temporal_case(ip, seed0 + k)
         except AssertionError as e:
             print("seed %d: MISMATCH %s" % (seed0 + k, e), flush=True)
             sys.exit(1)
