@@ -54,7 +54,8 @@ def test_farneback_pair_field(eng, shape, shift):
     err = np.abs(got.astype(np.float64) - ref.astype(np.float64))
     scale = max(1.0, float(np.abs(ref).max()))
     assert err.max() <= 1e-6 * scale, "max |dflow| = %g (flow scale %g)" % (err.max(), scale)
-    assert int((err > 0).sum()) <= 1e-5 * err.size, "%d of %d flow values differ" % (int((err > 0).sum()), err.size)
+    ndiff = int((err > 1e-12 * scale).sum())          # (residues of ~1e-30 in flat regions depend on the order of the f64 sums)
+    assert ndiff <= 1e-5 * err.size, "%d of %d flow values differ" % (ndiff, err.size)
     mref = float(np.mean(cref.flow_magnitude(ref)))
     mgot = float(np.mean(cref.flow_magnitude(got)))
     assert abs(mgot - mref) <= FLOW_RTOL * max(mref, 1e-30)
@@ -195,3 +196,5 @@ def test_randomised_parity_sweep(eng):
         msg = fuzz_parity.one_case(eng, seed)
         done += msg.startswith("ok")
     assert done >= 140
+    for seed in range(7000, 7080):                          # single pairs of any content, field against field
+        assert fuzz_parity.flow_case(eng, seed).startswith("ok")

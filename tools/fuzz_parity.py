@@ -59,6 +59,42 @@ def one_case(eng, seed, max_side=260):
         params["consecutive_threshold"])
 
 
+def flow_case(eng, seed):
+    """One Farneback pair of arbitrary content (white noise, constants, steps, shifted textures; sizes from 2x2,
+    so 1 to 4 pyramid levels and every resize path) against the oracle's field, value by value."""
+    from oracle import cref
+    rng = np.random.default_rng(seed)
+    h = int(rng.integers(2, 300)); w = int(rng.integers(2, 400))
+    kind = int(rng.integers(0, 5))
+    yy, xx = np.mgrid[0:h, 0:w].astype(np.float64)
+    if kind == 0:
+        a = rng.integers(0, 256, (h, w)); b = rng.integers(0, 256, (h, w))
+    elif kind == 1:
+        a = np.full((h, w), int(rng.integers(0, 256))); b = np.full((h, w), int(rng.integers(0, 256)))
+    elif kind == 2:
+        a = (xx > w / 2) * 255; b = (xx > w / 2 + float(rng.uniform(-9, 9))) * 255
+    else:
+        dx, dy = float(rng.uniform(-12, 12)), float(rng.uniform(-12, 12))
+        def tex(ox, oy):
+            v = 110.0 + np.zeros((h, w))
+            for kx, ky, ph in ((0.61, 0.23, 0.3), (0.17, 0.55, 1.1), (-0.41, 0.37, 2.0), (0.29, -0.47, 0.7)):
+                v += 14 * np.sin((xx - ox) * kx + (yy - oy) * ky + ph)
+            return v + rng.normal(0, float(rng.choice([0, 2, 10])), (h, w))
+        a = tex(0, 0); b = tex(dx, dy)
+    a = np.clip(np.rint(a), 0, 255).astype(np.float32); b = np.clip(np.rint(b), 0, 255).astype(np.float32)
+    ref = cref.farneback(a, b)
+    got = eng.farneback_pair(eng.to_device(a), eng.to_device(b)).cpu().numpy()
+    assert np.isfinite(got).all() == np.isfinite(ref).all(), "finiteness"
+    err = np.abs(got.astype(np.float64) - ref.astype(np.float64))
+    scale = max(1.0, float(np.abs(ref).max()))
+    # (flat regions: both fields are zero up to residues of ~1e-30 that depend on the order of the f64 sums)
+    diff = err > 1e-12 * scale
+    if diff.any():
+        assert err.max() <= 1e-6 * scale and diff.sum() <= max(1, 1e-5 * diff.size), \
+            "flow field %dx%d kind %d: %d of %d values differ, max %.3g (scale %.3g)" % (w, h, kind, diff.sum(), diff.size, err.max(), scale)
+    return "ok  %3dx%-3d kind %d: %d values differ" % (w, h, kind, int(diff.sum()))
+
+
 def main():
     from image_processing_amd.engine import Engine
     cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
@@ -70,6 +106,9 @@ def main():
         seed = seed0 + k
         try:
             msg = one_case(eng, seed, max_side)
+            fmsg = flow_case(eng, seed)
+            if not fmsg.endswith(": 0 values differ"):
+                print("seed %d: flow %s" % (seed, fmsg), flush=True)
         except AssertionError as e:
             print("seed %d: MISMATCH %s" % (seed, e), flush=True)
             sys.exit(1)
