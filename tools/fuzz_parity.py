@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Randomised parity sweep of the whole path against the CPU oracle (a checker, like tests/): random frame
 sizes (odd ones included), chunk lengths, parameter sets and scene contents.  Run on the GPU box:
-    python tools/fuzz_parity.py [cases] [seed] [max_side]
+    python tools/fuzz_parity.py [cases] [seed] [max_side] [wide]
 Prints one line per case and exits non-zero at the first mismatch (the case's seed reproduces it)."""
 import os
 import sys
@@ -18,7 +18,7 @@ def eq_nan(a, b):
     return np.array_equal(np.asarray(a, float), np.asarray(b, float), equal_nan=True)
 
 
-def one_case(eng, seed, max_side=260):
+def one_case(eng, seed, max_side=260, wide=False):
     from image_processing_amd import synth
     from oracle import pipeline
     rng = np.random.default_rng(seed)
@@ -27,6 +27,12 @@ def one_case(eng, seed, max_side=260):
                   flow_threshold=float(rng.choice([0.05, 0.5, 2.0, 4.0])), static_threshold=float(rng.choice([5, 20, 50])),
                   min_cluster_size=int(rng.integers(1, 4)), max_cluster_size=int(rng.integers(6, 40)),
                   min_circularity=float(rng.choice([0.0, 0.3, 0.6])), sliding_window_radius=int(rng.integers(1, 6)))
+    if wide:                                                 # the corners of the parameter space
+        n = int(rng.integers(2, 90))
+        params.update(consecutive_threshold=int(rng.integers(0, 8)), sliding_window_radius=int(rng.integers(1, 9)),
+                      max_cluster_size=int(rng.choice([1, 5, 40, 300])), min_cluster_size=int(rng.integers(0, 7)),
+                      min_circularity=float(rng.choice([0.0, 0.785, 1.0])), brightness_threshold=int(rng.choice([0, 100, 170, 254, 255])),
+                      static_threshold=float(rng.choice([0, 1, 50, 100])))
     motion = tuple(int(x) for x in rng.choice(np.arange(1, max(2, n)), size=min(int(rng.integers(0, 4)), max(1, n - 1)), replace=False)) if n > 2 else ()
     frames = synth.chunk_numpy(seed, n, h, w, hot=float(rng.uniform(2, 30)), stuck=int(rng.integers(0, 6)),
                                bright_block=bool(rng.integers(0, 2)), motion_at=motion, shift=float(rng.uniform(0.5, 9)),
@@ -100,12 +106,13 @@ def main():
     cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
     seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
     max_side = int(sys.argv[3]) if len(sys.argv) > 3 else 260
+    wide = len(sys.argv) > 4 and sys.argv[4] == "wide"
     eng = Engine(0)
     t0 = time.time()
     for k in range(cases):
         seed = seed0 + k
         try:
-            msg = one_case(eng, seed, max_side)
+            msg = one_case(eng, seed, max_side, wide)
             fmsg = flow_case(eng, seed)
             if not fmsg.endswith(": 0 values differ"):
                 print("seed %d: flow %s" % (seed, fmsg), flush=True)
