@@ -147,16 +147,31 @@ def load_video_frames(filename, frames_start=None, frames_end=None, grayscale=Tr
     # our own reader hands 8-bit streams over as they are stored (cv2 would expand them to grey-coded BGR and
     # the luma conversion would give the same bytes back)
     direct = grayscale and getattr(cap, "is_gray", lambda: False)()
+    pending = []                                        # positions in `frames` of colour frames not yet converted
+
+    def convert_pending():
+        # one upload / kernel / download for a batch of decoded colour frames instead of one per frame
+        if pending:
+            grey = _to_grey(np.stack([frames[k] for k in pending]))
+            for j, k in enumerate(pending):
+                frames[k] = grey[j]
+            del pending[:]
+
     while cap.isOpened():
         if frames_end and frame_idx >= frames_end:
             break
         ret, frame = cap.read_gray() if direct else cap.read()
         if not ret:
             break
-        if grayscale and len(frame.shape) == 3:
-            frame = _to_grey(frame)
         frames.append(frame)
+        if grayscale and len(frame.shape) == 3:
+            if pending and frame.shape != frames[pending[0]].shape:
+                convert_pending()
+            pending.append(len(frames) - 1)
+            if len(pending) == 32:
+                convert_pending()
         frame_idx += 1
+    convert_pending()
     cap.release()
     return frames
 

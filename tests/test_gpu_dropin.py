@@ -291,3 +291,22 @@ def test_randomised_labelling_stages_sweep():
     for seed in range(50000, 50200):
         assert fuzz_stages.one_case(ip, seed).startswith("ok")
         assert fuzz_stages.temporal_case(ip, seed) == "ok"
+
+
+def test_load_video_frames_colour_batches(tmp_path):
+    """Colour footage is converted on the GPU in batches of 32 decoded frames: same grey frames as the luma
+    restatement frame by frame, across batch boundaries and with a frame range."""
+    import image_processing as ip
+    from image_processing_amd import avi
+    from oracle import cref
+    rng = np.random.default_rng(12)
+    bgr = rng.integers(0, 256, (70, 20, 26, 3), dtype=np.uint8)
+    fn = str(tmp_path / "colour.avi")
+    avi.write_avi(fn, bgr, fps=10.0)
+    got = ip.load_video_frames(fn)
+    assert len(got) == 70 and all(g.shape == (20, 26) and g.dtype == np.uint8 for g in got)
+    assert np.array_equal(np.stack(got), np.stack([cref.bgr2gray_u8(f) for f in bgr]))
+    part = ip.load_video_frames(fn, frames_start=30, frames_end=67)
+    assert np.array_equal(np.stack(part), np.stack([cref.bgr2gray_u8(f) for f in bgr[30:67]]))
+    raw = ip.load_video_frames(fn, grayscale=False)
+    assert np.array_equal(np.stack(raw), bgr)
