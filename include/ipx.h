@@ -94,7 +94,8 @@ int ipx_bgr2gray(ipx_ctx *ctx, const uint8_t *bgr, size_t npix, uint8_t *gray);
 /* ---- a3: compute_optical_flow_metric, ip.py:852-873 --------------------------------------
  * flows[0] = 0 (or the metric against prev_frame when given: the left halo of a frame-range
  * shard); flows[i] = mean Farneback flow magnitude between frames i-1 and i, as float32
- * (np.mean of an f32 array).  keep[i] = (double)flows[i] <= flow_threshold (ip.py:559). */
+ * (np.mean of an f32 array).  keep[i] = (double)flows[i] <= flow_threshold (ip.py:559).
+ * Frames of 2x2 up to 2^26 pixels (IPX_ERR_UNSUPPORTED beyond: 32-bit buffer offsets). */
 int ipx_flow_metric(ipx_ctx *ctx, const uint8_t *frames, int n, int H, int W,
                     const uint8_t *prev_frame, float *flows, uint8_t *keep);
 /* One Farneback pair on float32 images, full flow field (H,W,2) out: unit parity of
