@@ -72,6 +72,8 @@ PROTOTYPES = {
     "ipx_damaged_mask": (_i, [_ctx, _p, _i, _i, _p, _i, _p, _p]),
     "ipx_detect_raw": (_i, [_ctx, _p, _i, _i, _i, _i, _i, _p, _p, _p, _p]),
     "ipx_remove_bright_regions": (_i, [_ctx, _p, _p, _i, _i, _i, _p]),
+    "ipx_noalloc_scratch_bytes": (C.c_size_t, []),
+    "ipx_remove_bright_regions_noalloc": (_i, [_ctx, _p, _p, _i, _i, _i, _p]),
     "ipx_persistent_mask": (_i, [_ctx, _p, _p, _i, _i, _i, _p]),
     "ipx_or_planes": (_i, [_ctx, _p, _i, _i, _i, _p]),
     "ipx_static_maps": (_i, [_ctx, _p, _p, _p, _p, _i, _i, _i, _p, _p]),

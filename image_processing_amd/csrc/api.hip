@@ -65,6 +65,7 @@ extern "C" int ipx_ctx_create(int device, ipx_ctx **out)
     IPX_CHECK_HIP(hipGetDeviceCount(&count));
     IPX_REQUIRE(device >= 0 && device < count, "no such device");
     IPX_CHECK_HIP(hipSetDevice(device));
+    IPX_TRY(ipx_static_scratch_init(device));
     ipx_ctx *c = new ipx_ctx();
     c->device = device;
     c->stream = nullptr;

@@ -426,19 +426,21 @@ constexpr size_t CCL_BUDGET = (size_t)8 << 30;     // ~490 planes of 1080p per l
 
 }  // namespace
 
-extern "C" int ipx_remove_bright_regions(ipx_ctx *ctx, const uint64_t *bright_bits, const uint64_t *damaged_bits,
-                                         int count, int H, int W, uint64_t *out_bits)
+// remove_bright_regions on `count` planes with the labelling scratch given by the caller of this function:
+// `scr` holds B planes' worth of (parent, aux0, remove plane).  Nothing in it has to start at zero: ccl_init
+// writes the parent / aux0 entry of every segment that exists in the plane at hand, later kernels touch only
+// those entries, and select_big writes every word of the `remove` plane.  `profiled` = 0 launches without the
+// built-in profiler (whose event pool grows by allocation).
+#define CCL_LAUNCH(profiled, kid, bytes, kernel, grid, block, ...)                              \
+    do {                                                                                       \
+        if (profiled) IPX_LAUNCH(ctx, kid, bytes, kernel, grid, block, __VA_ARGS__);           \
+        else hipLaunchKernelGGL(kernel, grid, block, 0, ctx->stream, __VA_ARGS__);             \
+    } while (0)
+
+static int remove_bright_regions_run(ipx_ctx *ctx, const Plane &pl, void *scr, int B, int profiled,
+                                     const uint64_t *bright_bits, const uint64_t *damaged_bits, int count,
+                                     uint64_t *out_bits)
 {
-    IPX_REQUIRE(ctx && bright_bits && damaged_bits && out_bits, "null pointer");
-    IPX_REQUIRE(count > 0 && H > 0 && W > 0, "bad sizes");
-    IPX_REQUIRE((size_t)H * ipx_wpr(W) * 64 < ((size_t)1 << 31), "frame too large for 32-bit segment ids");
-    if (int e = ipx_ctx_enter(ctx)) return e;
-    const Plane pl = make_plane(H, W);
-    // per plane: parent + aux0 (int32 per id) + one `remove` plane
-    const size_t per_plane = pl.ids * 8 + pl.words * 8;
-    const int B = ccl_batch(pl, count, per_plane, CCL_BUDGET);
-    void *scr;
-    if (int e = ipx_scratch(ctx, SLOT_CCL, per_plane * B, &scr)) return e;
     int *par = (int *)scr;
     int *aux0 = par + pl.ids * B;
     uint64_t *remove = (uint64_t *)(aux0 + pl.ids * B);
@@ -450,17 +452,85 @@ extern "C" int ipx_remove_bright_regions(ipx_ctx *ctx, const uint64_t *bright_bi
         uint64_t *ob = out_bits + first * pl.words;
         const size_t nw = pl.words * nb;
         const dim3 grid((unsigned)((nw + 255) / 256)), block(256);
-        IPX_LAUNCH(ctx, KID_CCL_INIT, nw * 8, ccl_init_kernel, grid, block, bb, pl, nb, par, aux0, (unsigned *)nullptr);
-        IPX_LAUNCH(ctx, KID_CCL_MERGE, nw * 8, ccl_merge_kernel, grid, block, bb, pl, nb, par);
-        IPX_LAUNCH(ctx, KID_CCL_REDUCE, nw * 8, ccl_area_kernel, grid, block, bb, pl, nb, par, aux0);
-        IPX_LAUNCH(ctx, KID_CCL_SELECT, nw * 16, select_big_kernel, grid, block, bb, pl, nb, par, aux0, min_area, remove);
-        IPX_LAUNCH(ctx, KID_CCL_INIT, nw * 8, ccl_init_kernel, grid, block, db, pl, nb, par, aux0, (unsigned *)nullptr);
-        IPX_LAUNCH(ctx, KID_CCL_MERGE, nw * 8, ccl_merge_kernel, grid, block, db, pl, nb, par);
-        IPX_LAUNCH(ctx, KID_CCL_REDUCE, nw * 16, ccl_taint_kernel, grid, block, db, remove, pl, nb, par, aux0);
-        IPX_LAUNCH(ctx, KID_CCL_SELECT, nw * 16, select_untainted_kernel, grid, block, db, pl, nb, par, aux0, ob);
+        CCL_LAUNCH(profiled, KID_CCL_INIT, nw * 8, ccl_init_kernel, grid, block, bb, pl, nb, par, aux0, (unsigned *)nullptr);
+        CCL_LAUNCH(profiled, KID_CCL_MERGE, nw * 8, ccl_merge_kernel, grid, block, bb, pl, nb, par);
+        CCL_LAUNCH(profiled, KID_CCL_REDUCE, nw * 8, ccl_area_kernel, grid, block, bb, pl, nb, par, aux0);
+        CCL_LAUNCH(profiled, KID_CCL_SELECT, nw * 16, select_big_kernel, grid, block, bb, pl, nb, par, aux0, min_area, remove);
+        CCL_LAUNCH(profiled, KID_CCL_INIT, nw * 8, ccl_init_kernel, grid, block, db, pl, nb, par, aux0, (unsigned *)nullptr);
+        CCL_LAUNCH(profiled, KID_CCL_MERGE, nw * 8, ccl_merge_kernel, grid, block, db, pl, nb, par);
+        CCL_LAUNCH(profiled, KID_CCL_REDUCE, nw * 16, ccl_taint_kernel, grid, block, db, remove, pl, nb, par, aux0);
+        CCL_LAUNCH(profiled, KID_CCL_SELECT, nw * 16, select_untainted_kernel, grid, block, db, pl, nb, par, aux0, ob);
         IPX_LAUNCH_CHECK();
     }
     return IPX_OK;
+}
+
+// per plane: parent + aux0 (int32 per id) + one `remove` plane
+static inline size_t rbr_bytes_per_plane(const Plane &pl) { return pl.ids * 8 + pl.words * 8; }
+
+extern "C" int ipx_remove_bright_regions(ipx_ctx *ctx, const uint64_t *bright_bits, const uint64_t *damaged_bits,
+                                         int count, int H, int W, uint64_t *out_bits)
+{
+    IPX_REQUIRE(ctx && bright_bits && damaged_bits && out_bits, "null pointer");
+    IPX_REQUIRE(count > 0 && H > 0 && W > 0, "bad sizes");
+    IPX_REQUIRE((size_t)H * ipx_wpr(W) * 64 < ((size_t)1 << 31), "frame too large for 32-bit segment ids");
+    if (int e = ipx_ctx_enter(ctx)) return e;
+    const Plane pl = make_plane(H, W);
+    const size_t per_plane = rbr_bytes_per_plane(pl);
+    const int B = ccl_batch(pl, count, per_plane, CCL_BUDGET);
+    void *scr;
+    if (int e = ipx_scratch(ctx, SLOT_CCL, per_plane * B, &scr)) return e;
+    return remove_bright_regions_run(ctx, pl, scr, B, 1, bright_bits, damaged_bits, count, out_bits);
+}
+
+// ---- the entry point that allocates nothing ----------------------------------------------------------------
+// Labelling scratch of ipx_remove_bright_regions_noalloc: one array per GPU the library runs on, held until the
+// process ends.  In host code the NAME below is only a handle for hipGetSymbolAddress: the device address is
+// resolved once per device by ipx_static_scratch_init (called from ipx_ctx_create with that device current) and
+// from then on only that pointer is used.
+static __device__ __align__(256) unsigned char scratch[IPX_NOALLOC_SCRATCH_BYTES];
+
+namespace {
+constexpr int MAX_DEVICES = 64;
+void *g_scratch_ptr[MAX_DEVICES];          // device address of `scratch` on device d, or null
+}
+
+// Called by ipx_ctx_create with `device` current.  Loading the code object (and with it the array) on a device
+// happens here at the latest, not inside the entry point.
+int ipx_static_scratch_init(int device)
+{
+    if (device < 0 || device >= MAX_DEVICES) return IPX_OK;           // such a device gets no no-alloc entry point
+    void *ptr = __atomic_load_n(&g_scratch_ptr[device], __ATOMIC_ACQUIRE);
+    if (ptr) return IPX_OK;
+    IPX_CHECK_HIP(hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch)));
+    __atomic_store_n(&g_scratch_ptr[device], ptr, __ATOMIC_RELEASE);   // every thread resolves the same address
+    return IPX_OK;
+}
+
+extern "C" size_t ipx_noalloc_scratch_bytes(void) { return IPX_NOALLOC_SCRATCH_BYTES; }
+
+extern "C" int ipx_remove_bright_regions_noalloc(ipx_ctx *ctx, const uint64_t *bright_bits, const uint64_t *damaged_bits,
+                                                 int count, int H, int W, uint64_t *out_bits)
+{
+    IPX_REQUIRE(ctx && bright_bits && damaged_bits && out_bits, "null pointer");
+    IPX_REQUIRE(count > 0 && H > 0 && W > 0, "bad sizes");
+    const Plane pl = make_plane(H, W);
+    const size_t per_plane = rbr_bytes_per_plane(pl);
+    if (per_plane > IPX_NOALLOC_SCRATCH_BYTES) {
+        ipx_set_error("ipx_remove_bright_regions_noalloc: a %d x %d plane needs %zu bytes of labelling scratch, the static "
+                      "array holds %zu (planes of up to %d 64-pixel words, e.g. 3840 x 2160); use ipx_remove_bright_regions",
+                      W, H, per_plane, (size_t)IPX_NOALLOC_SCRATCH_BYTES, IPX_NOALLOC_MAX_WORDS);
+        return IPX_ERR_UNSUPPORTED;
+    }
+    void *scr = (ctx->device >= 0 && ctx->device < MAX_DEVICES) ? __atomic_load_n(&g_scratch_ptr[ctx->device], __ATOMIC_ACQUIRE) : nullptr;
+    if (!scr) {
+        ipx_set_error("ipx_remove_bright_regions_noalloc: no static scratch on device %d", ctx->device);
+        return IPX_ERR_UNSUPPORTED;
+    }
+    if (int e = ipx_ctx_enter(ctx)) return e;
+    size_t B = IPX_NOALLOC_SCRATCH_BYTES / per_plane;
+    if (B > (size_t)count) B = count;
+    return remove_bright_regions_run(ctx, pl, scr, (int)B, 0, bright_bits, damaged_bits, count, out_bits);
 }
 
 extern "C" int ipx_cluster_stats(ipx_ctx *ctx, const uint8_t *frames, const uint64_t *mask_bits, const uint8_t *keep,

@@ -111,6 +111,9 @@ int ipx_ctx_enter(ipx_ctx *ctx);
 // Grows slot `s` to at least `bytes` (synchronises the stream before freeing the old arena).
 int ipx_scratch(ipx_ctx *ctx, int s, size_t bytes, void **out);
 void ipx_flow_plan_free(ipx_flow_plan *plan);
+// ccl.hip: resolves the device address of the static scratch of ipx_remove_bright_regions_noalloc on `device`
+// (which must be current); ipx_ctx_create calls it.
+int ipx_static_scratch_init(int device);
 
 static inline int ipx_wpr(int W) { return (W + 63) >> 6; }
 static inline size_t ipx_align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }

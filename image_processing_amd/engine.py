@@ -172,6 +172,13 @@ class Engine:
         check(lib.ipx_remove_bright_regions(self._ctx, _ptr(bright_bits), _ptr(damaged_bits), count, H, W, _ptr(out)))
         return out
 
+    def remove_bright_regions_noalloc(self, bright_bits, damaged_bits, H, W, out):
+        """ipx_remove_bright_regions_noalloc: the caller supplies ``out``; nothing is allocated."""
+        self._enter()
+        check(lib.ipx_remove_bright_regions_noalloc(self._ctx, _ptr(bright_bits), _ptr(damaged_bits),
+                                                    damaged_bits.shape[0], H, W, _ptr(out)))
+        return out
+
     def persistent_mask(self, raw_bits, keep, H, W):
         n = raw_bits.shape[0]
         out = self.empty_bits(1, H, W)[0]

@@ -126,6 +126,23 @@ int ipx_detect_raw(ipx_ctx *ctx, const uint8_t *frames, int n, int H, int W, int
 int ipx_remove_bright_regions(ipx_ctx *ctx, const uint64_t *bright_bits, const uint64_t *damaged_bits,
                               int count, int H, int W, uint64_t *out_bits);
 
+/* ---- the same for callers that cannot allocate --------------------------------------------
+ * No counterpart in the reference.  For callers that must not reach hipMalloc / hipFree: code under
+ * HIP graph capture, tight serving loops, harnesses that forbid allocation.  Same arguments, same
+ * kernels and bit-identical results as ipx_remove_bright_regions, but the labelling scratch
+ * (parent + accumulator per segment id and one `remove` plane per plane in flight) is a file-scope
+ * __device__ array of IPX_NOALLOC_SCRATCH_BYTES (65 MiB, one per GPU the library runs on, resolved
+ * by ipx_ctx_create) instead of the context's growable arena, and the built-in profiler is not
+ * applied to its launches.  Planes of more than IPX_NOALLOC_MAX_WORDS words (H * ceil(W/64); 3840 x
+ * 2160 has 129,600) are refused with IPX_ERR_UNSUPPORTED.  Every call on a GPU uses that GPU's one
+ * array: calls that overlap in time on one GPU (two streams, two contexts, two threads) race;
+ * calls ordered on one stream do not, and nothing has to be cleared between them. */
+#define IPX_NOALLOC_MAX_WORDS 131072
+#define IPX_NOALLOC_SCRATCH_BYTES ((size_t)IPX_NOALLOC_MAX_WORDS * (64 * 8 + 8))
+size_t ipx_noalloc_scratch_bytes(void);
+int ipx_remove_bright_regions_noalloc(ipx_ctx *ctx, const uint64_t *bright_bits, const uint64_t *damaged_bits,
+                                      int count, int H, int W, uint64_t *out_bits);
+
 /* ---- a9: compute_persistent_mask, ip.py:270-289 -------------------------------------------
  * Planes of discarded frames (keep[i] == 0, or all-zero planes when keep is NULL) reset the
  * runs, as the `None` entries do at ip.py:281-282.  A frame-range shard calls this on
