@@ -402,13 +402,16 @@ def compute_cluster_stats(frames, masks, flows, settings, n_jobs=-1):
     """ip.py:332-348 -> array of three float64 rows (cluster_count, cluster_size, cluster_brightness)."""
     n = len(masks)
     if not _pristine("filter_damaged_pixel_clusters"):                       # a caller replaced the stage
+        # Newer API generation (t.py:388-419): the settings carry the structuring element, which is the stage's
+        # 6th positional argument, and a discarded frame is an all-False mask instead of None.
+        extra = (settings.kernel,) if hasattr(settings, "kernel") else ()
         res = []
         for frame, mask, flow in zip(frames, masks, flows):
-            if mask is None or flow > settings.flow_threshold:
+            if mask is None or flow > settings.flow_threshold or (extra and not np.asarray(mask).any()):
                 res.append((0.0, 0.0, 0.0))
             else:
                 _, c, s, b = filter_damaged_pixel_clusters(frame, mask, settings.min_cluster_size,
-                                                           settings.max_cluster_size, settings.min_circularity)
+                                                           settings.max_cluster_size, settings.min_circularity, *extra)
                 res.append((c, s, b))
         return np.array(res).T
     res = np.zeros((n, 3), np.float64)
@@ -506,6 +509,18 @@ def detect_damaged_pixels(frames, chunk_index=0, plot=False, show_plots=False, s
     return r["total_counts"], r["cluster_counts"], r["avg_sizes"], r["avg_brightnesses"]
 
 
+def _positional_arity(fn):
+    """Number of positional parameters of a replaced stage (the two API generations differ in it)."""
+    import inspect
+    try:
+        ps = inspect.signature(fn).parameters.values()
+    except (TypeError, ValueError):
+        return None
+    if any(q.kind == q.VAR_POSITIONAL for q in ps):
+        return None
+    return sum(q.kind in (q.POSITIONAL_ONLY, q.POSITIONAL_OR_KEYWORD) for q in ps)
+
+
 def _detect_stagewise(frames, chunk_index, plot, show_plots, save_plots, output_folder,
                       visualise_damaged_pixels_plot, plot_damaged_pixels_plot, plot_heatmap_plot, params):
     """The same sequence, one module-global stage call at a time (used when a stage was replaced)."""
@@ -513,9 +528,13 @@ def _detect_stagewise(frames, chunk_index, plot, show_plots, save_plots, output_
     frames = np.asarray(frames)
     optical_flows = compute_optical_flow_metric(frames)
     raw_masks = np.full(len(frames), None, dtype=object)
+    batch_backgrounds = None
+    if not _pristine("compute_background") and _positional_arity(compute_background) == 2:
+        batch_backgrounds = compute_background(frames, settings.sliding_window_radius)   # newer form, t.py:513-514
     for i, frame in enumerate(frames):
         if optical_flows[i] <= settings.flow_threshold:
-            background = compute_background(frames, i, settings.sliding_window_radius)
+            background = batch_backgrounds[i] if batch_backgrounds is not None else \
+                compute_background(frames, i, settings.sliding_window_radius)
             raw_mask = _raw_damaged_mask(frame, background)
             raw_masks[i] = remove_bright_regions(background, settings.brightness_threshold, raw_mask,
                                                  settings.max_cluster_size)
@@ -537,24 +556,49 @@ def _detect_stagewise(frames, chunk_index, plot, show_plots, save_plots, output_
 # ---------------------------------------------------------------------------------------------
 # plots (ip.py:381-435, 936-1065, 1096-1133) -- presentation only, matplotlib optional
 # ---------------------------------------------------------------------------------------------
-def _generate_plots(frames, chunk_index, masks, counts, flows, settings, show_plots=True, save_plots=False,
-                    output_folder="results", visualise_damaged_pixels_plot=True, plot_damaged_pixels_plot=True,
-                    plot_heatmap_plot=True):
-    """ip.py:381-435."""
-    if visualise_damaged_pixels_plot:
+def _is_index(v):
+    return isinstance(v, (int, np.integer)) and not isinstance(v, (bool, np.bool_))
+
+
+def _generate_plots(frames, *args, **kwargs):
+    """ip.py:381-435: ``(frames, chunk_index, masks, counts, flows, settings, show_plots=True, ...)``.
+    Newer form (t.py:433-458): ``(frames, masks, counts, flows, settings)``, and the plot functions are then
+    called without a chunk index."""
+    names = ("show_plots", "save_plots", "output_folder", "visualise_damaged_pixels_plot",
+             "plot_damaged_pixels_plot", "plot_heatmap_plot")
+    legacy = "chunk_index" in kwargs or (len(args) >= 1 and (_is_index(args[0]) or args[0] is None) and len(args) >= 5)
+    if legacy:
+        lead = ["chunk_index", "masks", "counts", "flows", "settings"]
+    else:
+        lead = ["masks", "counts", "flows", "settings"]
+    if len(args) > len(lead) + len(names):
+        raise TypeError("_generate_plots: too many positional arguments")
+    opts = dict(show_plots=True, save_plots=False, output_folder="results", visualise_damaged_pixels_plot=True,
+                plot_damaged_pixels_plot=True, plot_heatmap_plot=True)
+    bound = dict(zip(lead + list(names), args))
+    for k, v in kwargs.items():
+        if k in bound:
+            raise TypeError("_generate_plots: %s given twice" % k)
+        bound[k] = v
+    missing = [k for k in lead if k not in bound]
+    if missing:
+        raise TypeError("_generate_plots: missing %s" % ", ".join(missing))
+    opts.update({k: bound[k] for k in names if k in bound})
+    masks, counts, flows, settings = (bound[k] for k in ("masks", "counts", "flows", "settings"))
+    chunk = (bound["chunk_index"],) if legacy else ()
+    out = dict(show_plots=opts["show_plots"], save_plots=opts["save_plots"], output_folder=opts["output_folder"])
+    if opts["visualise_damaged_pixels_plot"]:
         survivors = [i for i, flow in enumerate(flows) if flow <= settings.flow_threshold]
         for i in survivors[:settings.number_of_plots]:
-            visualise_damaged_pixels(frames[i], i, chunk_index, masks[i], counts[i], show_plots=show_plots,
-                                     save_plots=save_plots, output_folder=output_folder)
-    if plot_damaged_pixels_plot:
-        plot_damaged_pixels(counts, chunk_index, show_plots=show_plots, save_plots=save_plots,
-                            output_folder=output_folder)
-    if plot_heatmap_plot:
+            visualise_damaged_pixels(frames[i], i, *chunk, masks[i], counts[i], **out)
+    if opts["plot_damaged_pixels_plot"]:
+        plot_damaged_pixels(counts, *chunk, **out)
+    if opts["plot_heatmap_plot"]:
         shape = np.asarray(frames[0]).shape
         heatmap = find_damaged_pixel_heatmap(
             frames, [np.asarray(m).astype(bool) if m is not None else np.zeros(shape, bool) for m in masks],
             settings.brightness_threshold)
-        plot_heatmap(heatmap, chunk_index, show_plots=show_plots, save_plots=save_plots, output_folder=output_folder)
+        plot_heatmap(heatmap, *chunk, **out)
 
 
 def _blend(base, overlay):
@@ -562,9 +606,21 @@ def _blend(base, overlay):
     return np.clip(np.rint(base.astype(np.float64) * 0.8 + overlay.astype(np.float64)), 0, 255).astype(np.uint8)
 
 
-def visualise_damaged_pixels(frame, frame_index, chunk_index, cluster_mask, cluster_count, bright_threshold=170,
-                             show_plots=True, save_plots=False, output_folder="results"):
-    """ip.py:936-1002: the frame next to a copy with damaged pixels and bright areas overlaid."""
+def visualise_damaged_pixels(frame, frame_index, *args, **kwargs):
+    """ip.py:936-1002: the frame next to a copy with damaged pixels and bright areas overlaid.
+    ``(frame, frame_index, chunk_index, cluster_mask, cluster_count, bright_threshold=170, show_plots=True,
+    save_plots=False, output_folder="results")``; the newer generation omits ``chunk_index`` (t.py:443-444)."""
+    legacy = "chunk_index" in kwargs or (len(args) >= 1 and _is_index(args[0]))
+    lead = (["chunk_index"] if legacy else []) + ["cluster_mask", "cluster_count", "bright_threshold", "show_plots",
+                                                   "save_plots", "output_folder"]
+    if len(args) > len(lead):
+        raise TypeError("visualise_damaged_pixels: too many positional arguments")
+    b = dict(chunk_index=None, bright_threshold=170, show_plots=True, save_plots=False, output_folder="results")
+    b.update(zip(lead, args))
+    b.update(kwargs)
+    chunk_index, cluster_mask, cluster_count = b["chunk_index"], b["cluster_mask"], b["cluster_count"]
+    bright_threshold, show_plots, save_plots, output_folder = (b["bright_threshold"], b["show_plots"], b["save_plots"],
+                                                               b["output_folder"])
     if not HAS_MATPLOTLIB:
         print("matplotlib not available - skipping damaged pixel visualisation")
         return
@@ -599,9 +655,9 @@ def visualise_damaged_pixels(frame, frame_index, chunk_index, cluster_mask, clus
     plt.close()
 
 
-def plot_heatmap(heatmap, chunk_index, title="Damaged Pixel Heatmap", show_plots=True, save_plots=False,
+def plot_heatmap(heatmap, chunk_index=None, title="Damaged Pixel Heatmap", show_plots=True, save_plots=False,
                  output_folder="results", figsize=(15, 10)):
-    """ip.py:1005-1032."""
+    """ip.py:1005-1032 (``chunk_index`` is optional: the newer generation calls it without, t.py:450-451)."""
     if not HAS_MATPLOTLIB:
         print("matplotlib not available - skipping heatmap plot")
         return
@@ -618,8 +674,9 @@ def plot_heatmap(heatmap, chunk_index, title="Damaged Pixel Heatmap", show_plots
     plt.close()
 
 
-def plot_damaged_pixels(damaged_pixel_counts, chunk_index, show_plots=True, save_plots=False, output_folder="results"):
-    """ip.py:1035-1065."""
+def plot_damaged_pixels(damaged_pixel_counts, chunk_index=None, show_plots=True, save_plots=False,
+                        output_folder="results"):
+    """ip.py:1035-1065 (``chunk_index`` is optional: the newer generation calls it without, t.py:445-447)."""
     if not HAS_MATPLOTLIB:
         print("matplotlib not available - skipping damaged pixel output graph")
         return
@@ -778,6 +835,22 @@ def _submit_chunk(chunk, idx, kw):
     return finish
 
 
+def _checkpoint_fingerprint(video_filename, num_frames, step_size, params):
+    """What a checkpointed chunk depends on: the video file (name, size, modification time, frame count), the
+    chunking, the effective settings and the library version."""
+    import json
+    from image_processing_amd import _ipx
+    try:
+        st = os.stat(video_filename)
+        ident = [os.path.basename(str(video_filename)), int(st.st_size), int(st.st_mtime_ns)]
+    except OSError:
+        ident = [os.path.basename(str(video_filename)), -1, -1]
+    settings = _prepare_settings(params)
+    eff = {k: getattr(settings, k) for k in sorted(_hostmath.DEFAULT_SETTINGS) if k != "number_of_plots"}
+    return json.dumps(dict(video=ident, frames=int(num_frames), step_size=int(step_size), settings=eff,
+                           ipx_version=int(_ipx.lib.ipx_version())), sort_keys=True, default=float)
+
+
 def main(video_filename, average_time=1.0, max_chunks=None, step_size=1000, plot=False, show_plots=False,
          save_plots=False, output_folder="results", visualise_damaged_pixels_plot=True, plot_damaged_pixels_plot=True,
          plot_heatmap_plot=True, params=None, *, checkpoint_folder=None):
@@ -785,8 +858,10 @@ def main(video_filename, average_time=1.0, max_chunks=None, step_size=1000, plot
     averages (``average_time`` seconds each) of the four per-frame series, plus the window mid-times.
 
     ``checkpoint_folder`` (not in the reference, which keeps everything in RAM until the end): every finished
-    chunk's four series are written to ``chunk_<start>_<end>.npz`` there, and a chunk whose file already
-    exists is neither decoded nor processed again (resume after an interruption; no plots for such chunks)."""
+    chunk's four series are written to ``chunk_<start>_<end>.npz`` there together with a fingerprint of the
+    video file, the chunking, the settings and the library version; a chunk whose file exists AND carries this
+    run's fingerprint is neither decoded nor processed again (resume after an interruption; no plots for such
+    chunks); any other file of that name is recomputed and overwritten."""
     num_frames, FPS = _video_info(video_filename)
     edges = np.arange(0, num_frames, step_size)
     if edges[-1] != num_frames:
@@ -803,23 +878,31 @@ def main(video_filename, average_time=1.0, max_chunks=None, step_size=1000, plot
     def ckpt_path(span):
         return os.path.join(checkpoint_folder, "chunk_%09d_%09d.npz" % span) if checkpoint_folder else None
 
+    fingerprint = _checkpoint_fingerprint(video_filename, num_frames, step_size, params) if checkpoint_folder else ""
+
     def from_checkpoint(span):
+        """The chunk's four series if its file was written for THIS video, chunking and parameter set by this
+        library version; anything else (missing, other fingerprint, unreadable) means: compute it."""
         path = ckpt_path(span)
-        if path and os.path.exists(path):
+        if not path or not os.path.exists(path):
+            return None
+        try:
             with np.load(path) as z:
-                if int(z["n_frames"]) == span[1] - span[0]:
-                    return tuple(z[k] for k in ("total_counts", "cluster_counts", "avg_sizes", "avg_brightnesses"))
-        return None
+                if str(z["fingerprint"]) != fingerprint or int(z["n_frames"]) != span[1] - span[0]:
+                    return None
+                return tuple(z[k] for k in ("total_counts", "cluster_counts", "avg_sizes", "avg_brightnesses"))
+        except Exception:                               # noqa: BLE001 - truncated / foreign file: recompute, overwrite
+            return None
 
     def collect(res, span=None):
         for store, series in zip(per_chunk, res):
             store.append(series)
         path = ckpt_path(span) if span else None
-        if path and not os.path.exists(path):
+        if path:                                        # computed in this run: (over)write
             os.makedirs(checkpoint_folder, exist_ok=True)
             tmp = path + ".tmp.npz"
             np.savez(tmp, total_counts=res[0], cluster_counts=res[1], avg_sizes=res[2], avg_brightnesses=res[3],
-                     n_frames=span[1] - span[0])
+                     n_frames=span[1] - span[0], fingerprint=fingerprint)
             os.replace(tmp, path)
 
     # Double-buffered streaming: a second thread decodes chunk k+1 (into pinned memory) while chunk k is on
@@ -868,8 +951,9 @@ _ORIG["detect_damaged_pixels"] = detect_damaged_pixels
 _ORIG["load_video_frames"] = load_video_frames
 
 
-def _cli(argv=None):
-    """The reference's command line (ip.py:1250-1350): same flags, every value a string."""
+def _cli_options(argv=None):
+    """Parse the reference's command line (ip.py:1250-1316: same flags, every value a string) into
+    dict(video_filename, main_kwargs, show_plots, save_plots, average_plots)."""
     import argparse
     parser = argparse.ArgumentParser()
     parser.add_argument("-vf", "--video_filename", help="Path to the AVI file")
@@ -915,8 +999,7 @@ def _cli(argv=None):
         "sliding_window_radius": num(args.sliding_window_radius, int, 3),
         "number_of_plots": num(args.number_of_plots, int, 20),
     }
-    results = main(
-        args.video_filename if args.video_filename else "11_01_H_170726081325.avi",
+    main_kwargs = dict(
         average_time=num(args.average_time, float, 1.0), max_chunks=max_chunks,
         step_size=num(args.step_size, int, 1000), plot=plot, show_plots=show_plots, save_plots=save_plots,
         output_folder=output_folder,
@@ -924,7 +1007,17 @@ def _cli(argv=None):
         plot_damaged_pixels_plot=flag(args.plot_damaged_pixels_plot, True),
         plot_heatmap_plot=flag(args.plot_heatmap_plot, True), params=params,
         checkpoint_folder=args.checkpoint_folder or None)
-    if flag(args.average_plots, True) and HAS_MATPLOTLIB:
+    return dict(video_filename=args.video_filename if args.video_filename else "11_01_H_170726081325.avi",
+                main_kwargs=main_kwargs, show_plots=show_plots, save_plots=save_plots,
+                average_plots=flag(args.average_plots, True))
+
+
+def _cli(argv=None):
+    """The reference's command line (ip.py:1250-1350)."""
+    opts = _cli_options(argv)
+    show_plots, save_plots, output_folder = opts["show_plots"], opts["save_plots"], opts["main_kwargs"]["output_folder"]
+    results = main(opts["video_filename"], **opts["main_kwargs"])
+    if opts["average_plots"] and HAS_MATPLOTLIB:
         plot_all_chunks(results["averages_counts"], results["averages_clusters"], results["averages_size"],
                         results["averages_brightness"], results["times"], show_plots=show_plots,
                         save_plots=save_plots, output_folder=output_folder)

@@ -71,9 +71,17 @@ def build_lib(force=False, verbose=False):
             raise RuntimeError("hipcc failed on %s" % s)
         if verbose and out:
             sys.stderr.write(out.decode(errors="replace"))
-    if procs or force:
-        _check_isa(verbose)
     if force or procs or _stale(LIB, objs):
+        # The ISA check guards the LINK: it runs whenever a library is about to be made, also when the objects
+        # are left over from an invocation whose check failed.  On failure the objects go, so that no later
+        # build can link them unchecked.
+        try:
+            _check_isa(verbose)
+        except Exception:
+            for o in objs + [LIB]:
+                if os.path.exists(o):
+                    os.remove(o)
+            raise
         cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
         if verbose:
             print(" ".join(cmd))

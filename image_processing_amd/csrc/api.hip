@@ -71,6 +71,8 @@ extern "C" int ipx_ctx_create(int device, ipx_ctx **out)
     c->stream = nullptr;
     for (int i = 0; i < SLOT_COUNT; ++i) { c->slot[i] = nullptr; c->slot_bytes[i] = 0; }
     c->flow_plan = nullptr;
+    c->fi_spin_limit = 1u << 27;
+    c->flow_ran = 0;
     memset(&c->prof, 0, sizeof(c->prof));
     ipx_default_params(&c->p);
     hipError_t e = hipEventCreate(&c->ev0);
@@ -149,6 +151,13 @@ extern "C" int ipx_synchronize(ipx_ctx *ctx)
     IPX_REQUIRE(ctx, "null pointer");
     if (int e = ipx_ctx_enter(ctx)) return e;
     IPX_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+    int raised = 0;
+    IPX_TRY(ipx_flow_status(ctx, &raised, 0));
+    if (raised) {
+        ipx_set_error("flow stage: a hand-off inside flow_iter_kernel timed out; its metrics were reported as NaN "
+                      "(frames discarded).  ipx_flow_status(ctx, &r, 1) clears the condition");
+        return IPX_ERR_HIP;
+    }
     return IPX_OK;
 }
 

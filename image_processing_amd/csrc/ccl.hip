@@ -164,7 +164,7 @@ __global__ void ccl_area_kernel(const uint64_t *bits, Plane pl, int count, int *
 __global__ void select_big_kernel(const uint64_t *bits, Plane pl, int count, const int *par, const int *aux0,
                                   int min_area, uint64_t *out)
 {
-    IPX_VGPR_PAD(16);
+    IPX_VGPR_PAD_SAFE();
     const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= pl.words * count) return;
     uint64_t rem = bits[g];
@@ -210,7 +210,7 @@ __global__ void ccl_taint_kernel(const uint64_t *bits, const uint64_t *remove, P
 __global__ void select_untainted_kernel(const uint64_t *bits, Plane pl, int count, const int *par, const int *aux0,
                                         uint64_t *out)
 {
-    IPX_VGPR_PAD(16);
+    IPX_VGPR_PAD_SAFE();
     const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= pl.words * count) return;
     uint64_t rem = bits[g];
@@ -384,7 +384,7 @@ __global__ void cluster_eval_kernel(const uint64_t *bits, Plane pl, int count, c
 __global__ void select_marked_kernel(const uint64_t *bits, Plane pl, int count, const int *par, const int *aux0,
                                      uint64_t *out)
 {
-    IPX_VGPR_PAD(16);
+    IPX_VGPR_PAD_SAFE();
     const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= pl.words * count) return;
     uint64_t rem = bits[g];

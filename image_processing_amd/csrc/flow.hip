@@ -623,6 +623,8 @@ struct FiArgs {
     int sh, sw;
     const int *x_ofs, *y_ofs;
     const float *x_a, *y_b;
+    unsigned *err;              // device error word of the flow stage (bit 0: a consumer hand-off timed out)
+    unsigned spin_limit;        // polls a consumer wave waits for its partners before it gives up
 };
 
 struct FiVec {                  // a flow vector in flight: IN 0 uses p00 only
@@ -818,10 +820,16 @@ __global__ __launch_bounds__(FI_THREADS, 4) void flow_iter_kernel(const FiArgs a
         flag_target += 4;
         if ((tid & 63) == 0) __hip_atomic_fetch_add(s_flag, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
         // every consumer wave posts once per step, so the wait ends; the bound only keeps a future protocol
-        // error from hanging the GPU (it is ~10 s of polling)
+        // error from hanging the GPU (~10 s of polling at the default limit).  Running into it is not silent:
+        // the stage's error word is raised, magnitude_finish_kernel then reports NaN metrics with keep = 0 and
+        // ipx_synchronize / ipx_flow_status return IPX_ERR_HIP.
         unsigned spins = 0;
-        while (__hip_atomic_load(s_flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < flag_target && ++spins < (1u << 27))
+        bool met;
+        while (!(met = __hip_atomic_load(s_flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) >= flag_target) && spins < a.spin_limit) {
+            ++spins;
             __builtin_amdgcn_s_sleep(1);
+        }
+        if (!met && (tid & 63) == 0) atomicOr(a.err, 1u);
     };
 
 #ifdef IPX_FI_STAMPS
@@ -946,13 +954,15 @@ __global__ __launch_bounds__(FI_THREADS, 4) void flow_iter_kernel(const FiArgs a
 }
 
 // mean magnitude: the per-workgroup partial sums (f64) of the last iteration, added in a fixed order
-__global__ void magnitude_finish_kernel(const double *partial, int nparts, size_t P, int npairs, double thr, float *flows, uint8_t *keep)
+__global__ void magnitude_finish_kernel(const double *partial, int nparts, size_t P, int npairs, double thr, float *flows, uint8_t *keep,
+                                        const unsigned *err)
 {
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= npairs) return;
     double s = 0.0;
     for (int i = 0; i < nparts; ++i) s += partial[(size_t)p * nparts + i];
-    const float m = (float)(s / (double)P);                // np.mean of an f32 array is f32
+    float m = (float)(s / (double)P);                      // np.mean of an f32 array is f32
+    if (*err) m = __builtin_nanf("");                      // the stage failed (flow_iter_kernel: consumers_sync): no metric
     flows[p] = m;
     if (keep) keep[p] = (double)m <= thr;                  // ip.py:559 (NaN compares false: discarded)
 }
@@ -1151,7 +1161,8 @@ int fi_partials(const ipx_flow_plan *pl, int np)
 
 // Flow of `np` pairs; pair p = launch frames (p, p+1).  Either the level-0 field (*uv_out) or, when
 // uv_out is null, `fi_partials` partial sums of its magnitudes per pair in `partial`.
-int run_pairs(ipx_ctx *ctx, const uint8_t *frames, const uint8_t *extra, int first, int np, float2 **uv_out, double *partial)
+int run_pairs(ipx_ctx *ctx, const uint8_t *frames, const uint8_t *extra, int first, int np, float2 **uv_out, double *partial,
+              unsigned *err)
 {
     const ipx_flow_plan *pl = ctx->flow_plan;
     const int nf = np + 1;
@@ -1173,6 +1184,7 @@ int run_pairs(ipx_ctx *ctx, const uint8_t *frames, const uint8_t *extra, int fir
         a.R = R; a.partial = partial;
         a.h = g.lh; a.w = g.lw; a.seg_rows = f.seg_rows; a.strips = f.strips; a.nseg = f.nseg; a.np = np; a.ppx = f.ppx;
         a.sh = a.sw = 0; a.x_ofs = a.y_ofs = nullptr; a.x_a = a.y_b = nullptr;
+        a.err = err; a.spin_limit = ctx->fi_spin_limit;
         for (int it = 0; it < 3; ++it) {                            // ip.py:864 iterations=3
             a.flow_in = cur; a.flow_out = other;
             const bool reduce = !uv_out && k == 0 && it == 2;
@@ -1208,7 +1220,44 @@ int pair_batch(int H, int W, int want)
     return (int)b;
 }
 
+// SLOT_FLOW_RED = [error word (256 bytes) | partial sums].  The word is cleared when the slot is (re)made and
+// stays raised once a kernel has raised it (sticky until ipx_flow_status(..., clear) or a new arena).
+int flow_red(ipx_ctx *ctx, size_t partial_bytes, void **partial, unsigned **err)
+{
+    const bool fresh = ctx->slot_bytes[SLOT_FLOW_RED] < partial_bytes + 256;
+    void *base;
+    IPX_TRY(ipx_scratch(ctx, SLOT_FLOW_RED, partial_bytes + 256, &base));
+    if (fresh) IPX_CHECK_HIP(hipMemsetAsync(base, 0, 256, ctx->stream));
+    *err = (unsigned *)base;
+    *partial = (char *)base + 256;
+    ctx->flow_ran = 1;
+    return IPX_OK;
+}
+
 }  // namespace
+
+// Reads the flow stage's error word (synchronises the stream).  *raised = 1 when a flow_iter hand-off has timed out
+// since the word was last cleared.
+extern "C" int ipx_flow_status(ipx_ctx *ctx, int *raised, int clear)
+{
+    IPX_REQUIRE(ctx && raised, "null pointer");
+    IPX_TRY(ipx_ctx_enter(ctx));
+    *raised = 0;
+    if (!ctx->flow_ran || !ctx->slot[SLOT_FLOW_RED]) return IPX_OK;
+    unsigned w = 0;
+    IPX_CHECK_HIP(hipMemcpyAsync(&w, ctx->slot[SLOT_FLOW_RED], sizeof(w), hipMemcpyDeviceToHost, ctx->stream));
+    IPX_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+    *raised = w != 0;
+    if (w && clear) IPX_CHECK_HIP(hipMemsetAsync(ctx->slot[SLOT_FLOW_RED], 0, sizeof(w), ctx->stream));
+    return IPX_OK;
+}
+
+extern "C" int ipx_debug_fi_spin_limit(ipx_ctx *ctx, unsigned limit)
+{
+    IPX_REQUIRE(ctx, "null pointer");
+    ctx->fi_spin_limit = limit;
+    return IPX_OK;
+}
 
 extern "C" int ipx_flow_metric(ipx_ctx *ctx, const uint8_t *frames, int n, int H, int W,
                                const uint8_t *prev_frame, float *flows, uint8_t *keep)
@@ -1226,13 +1275,14 @@ extern "C" int ipx_flow_metric(ipx_ctx *ctx, const uint8_t *frames, int n, int H
     void *red;
     const LevelGeom &g0 = ctx->flow_plan->lv[0];             // upper bound of fi_partials for any batch size
     const size_t max_parts = (size_t)((g0.lw + FI_TW - 1) / FI_TW) * ((g0.lh + 63) / 64);
-    IPX_TRY(ipx_scratch(ctx, SLOT_FLOW_RED, (size_t)B * max_parts * sizeof(double), &red));
+    unsigned *err;
+    IPX_TRY(flow_red(ctx, (size_t)B * max_parts * sizeof(double), &red, &err));
     for (int i0 = first_pair; i0 < n; i0 += B) {
         const int np = n - i0 < B ? n - i0 : B;
         const int nparts = fi_partials(ctx->flow_plan, np);
-        IPX_TRY(run_pairs(ctx, frames, prev_frame, i0 - 1, np, nullptr, (double *)red));
+        IPX_TRY(run_pairs(ctx, frames, prev_frame, i0 - 1, np, nullptr, (double *)red, err));
         IPX_LAUNCH(ctx, KID_MISC, 8.0 * nparts * np, magnitude_finish_kernel, dim3((np + 63) / 64), dim3(64), (const double *)red, nparts, P, np,
-                           ctx->p.flow_threshold, flows + i0, keep ? keep + i0 : nullptr);
+                           ctx->p.flow_threshold, flows + i0, keep ? keep + i0 : nullptr, (const unsigned *)err);
         IPX_LAUNCH_CHECK();
     }
     return IPX_OK;
@@ -1288,7 +1338,10 @@ extern "C" int ipx_farneback_pair(ipx_ctx *ctx, const float *prev, const float *
         return IPX_ERR_UNSUPPORTED;
     }
     float2 *uv;
-    IPX_TRY(run_pairs(ctx, u8, nullptr, 0, 1, &uv, nullptr));
+    void *red;
+    unsigned *err;
+    IPX_TRY(flow_red(ctx, 256, &red, &err));
+    IPX_TRY(run_pairs(ctx, u8, nullptr, 0, 1, &uv, nullptr, err));
     IPX_CHECK_HIP(hipMemcpyAsync(flow, uv, P * sizeof(float2), hipMemcpyDeviceToDevice, ctx->stream));
     return IPX_OK;
 }

@@ -49,6 +49,8 @@ struct ipx_ctx {
     size_t slot_bytes[SLOT_COUNT];
     hipEvent_t ev0, ev1;
     ipx_flow_plan *flow_plan;   // cached tables for the last (H,W) seen by the flow stage
+    unsigned fi_spin_limit;     // flow_iter_kernel: polls of the consumers' hand-off before it is given up (error word)
+    int flow_ran;               // the flow stage has used SLOT_FLOW_RED (whose first word is its error word)
     ipx_prof prof;
 };
 
@@ -77,6 +79,11 @@ void ipx_prof_end(ipx_ctx *ctx);
 // so the allocation grows by a granule and the shift operand is no longer the last register.  The check runs
 // at every build.
 #define IPX_VGPR_PAD(n) asm volatile("; v" #n " kept allocated (tools/check_shift64.py)" ::: "v" #n)
+// The register the three affected kernels keep allocated: v62 makes next_free_vgpr 63, so the wave is given 64
+// registers (still 8 waves per SIMD) of which the last, v63, is never handed out by the compiler: whatever
+// register a shift amount lives in, it is not the last one of the allocation.  Independent of how many registers
+// the kernel's code needs (as long as that is fewer than 62; the build's ISA scan fails otherwise).
+#define IPX_VGPR_PAD_SAFE() IPX_VGPR_PAD(62)
 
 void ipx_set_error(const char *fmt, ...);
 

@@ -71,6 +71,12 @@ class Engine:
     def synchronize(self):
         check(lib.ipx_synchronize(self._ctx))
 
+    def flow_status(self, clear=True):
+        """True when the flow stage's error word is raised (include/ipx.h: ipx_flow_status)."""
+        r = C.c_int()
+        check(lib.ipx_flow_status(self._ctx, C.byref(r), int(bool(clear))))
+        return bool(r.value)
+
     def to_device(self, a, dtype=None):
         t = torch.from_numpy(np.ascontiguousarray(a, dtype=dtype))
         return t.to(self.device, non_blocking=False)
@@ -281,7 +287,7 @@ class Engine:
         keep = d["keep"].cpu().numpy()
         counts = d["counts"].cpu().numpy()
         cluster = d["cluster"].cpu().numpy()
-        flows = d["flows"].cpu().numpy().astype(np.float64)
+        flows = _check_flows(d["flows"].cpu().numpy().astype(np.float64))
         total, cc, cs, cb = hostmath.chunk_results(keep, counts, cluster, H * W)
         out = dict(total_counts=total, cluster_counts=cc, avg_sizes=cs, avg_brightnesses=cb, flows=flows, keep=keep,
                    counts=counts, cluster=cluster)
@@ -289,6 +295,15 @@ class Engine:
             m = self.unpack_mask(d["final_bits"], H, W).cpu().numpy().astype(bool)
             out["final_masks"] = [m[i] if keep[i] else None for i in range(n)]
         return out
+
+
+def _check_flows(flows):
+    """libipx reports a failure inside the flow stage's kernels as NaN metrics (include/ipx.h, ipx_flow_metric);
+    uint8 footage cannot produce a NaN metric otherwise."""
+    if np.isnan(flows).any():
+        raise RuntimeError("libipx: the flow stage failed on the GPU (a hand-off inside flow_iter_kernel timed out); "
+                           "no result for this chunk")
+    return flows
 
 
 class _PendingChunk:
@@ -320,7 +335,7 @@ class _PendingChunk:
         cluster = self.host["cluster"].numpy()
         total, cc, cs, cb = hostmath.chunk_results(keep, counts, cluster, self.n_pixels)
         out = dict(total_counts=total, cluster_counts=cc, avg_sizes=cs, avg_brightnesses=cb,
-                   flows=self.host["flows"].numpy().astype(np.float64), keep=keep.copy(), counts=counts.copy(),
+                   flows=_check_flows(self.host["flows"].numpy().astype(np.float64)), keep=keep.copy(), counts=counts.copy(),
                    cluster=cluster.copy())
         self.dev = self.frames = None
         return out

@@ -74,3 +74,16 @@ def chunk_results(keep, counts, cluster, n_pixels):
         else:
             cbright[i] = np.nan                     # ip.py:680 / 707
     return total, ccount, csize, cbright
+
+
+def flow_margin(flows, flow_threshold, rel=1e-3):
+    """How close the motion test comes to its threshold over a chunk (ip.py:559: flow <= flow_threshold keeps a
+    frame): min |flow - threshold| over frames 1.. (frame 0's metric is the constant 0), and the number of frames
+    within ``rel`` relative of the threshold.  The quantitative cover for a discard list that rests on float
+    metrics: a margin far above the metric's tolerance means no frame can flip."""
+    f = np.asarray(flows, dtype=np.float64)[1:]
+    f = f[np.isfinite(f)]
+    if f.size == 0:
+        return dict(min_margin=float("inf"), frames_within_rel=0, rel=rel)
+    d = np.abs(f - float(flow_threshold))
+    return dict(min_margin=float(d.min()), frames_within_rel=int((d <= rel * abs(float(flow_threshold))).sum()), rel=rel)

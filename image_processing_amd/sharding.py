@@ -38,6 +38,7 @@ class _Solo:
     """Collectives of a world of one (no process group needed)."""
     world = 1
     rank = 0
+    exchange = False                                     # no rank to exchange with: the collective steps are skipped
 
     def all_gather(self, t):
         return [t]
@@ -47,40 +48,76 @@ class _Solo:
 
 
 class _Dist:
-    def __init__(self, group=None):
+    def __init__(self, group=None, forced=False):
         import torch.distributed as dist
         self.dist = dist
+        self.calls = 0                                   # collectives issued (bench.py reports them per chunk)
+        self.bytes = 0                                   # payload bytes this rank contributed
+        self.timed = False                               # set: every collective is bracketed by events on its stream
+        self._events = []
         self.group = group
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
         # RCCL ("nccl") moves device tensors directly; gloo (CPU rehearsals of the multi-rank path) is given
         # host copies, because it has no device all_gather
         self.stage = dist.get_backend(group) == "gloo"
+        # a world of one normally skips the exchanges; `forced` runs every collective all the same
+        self.exchange = self.world > 1 or bool(forced)
+
+    def _bracket(self, t):
+        if not (self.timed and t.is_cuda):
+            return None
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        self._events.append((e0, e1))
+        return e1
+
+    def collective_ms(self, reset=True):
+        """GPU time between the start and the end of every timed collective since the last reset (synchronises)."""
+        torch.cuda.synchronize()
+        ms = sum(a.elapsed_time(b) for a, b in self._events)
+        if reset:
+            self._events, self.calls, self.bytes = [], 0, 0
+        return ms
 
     def all_gather(self, t):
+        self.calls += 1
+        self.bytes += t.numel() * t.element_size()
+        end = self._bracket(t)
         if self.stage and t.is_cuda:
             h = t.contiguous().cpu()
             out = [torch.empty_like(h) for _ in range(self.world)]
             self.dist.all_gather(out, h, group=self.group)
-            return [o.to(t.device) for o in out]
-        out = [torch.empty_like(t) for _ in range(self.world)]
-        self.dist.all_gather(out, t.contiguous(), group=self.group)
+            out = [o.to(t.device) for o in out]
+        else:
+            out = [torch.empty_like(t) for _ in range(self.world)]
+            self.dist.all_gather(out, t.contiguous(), group=self.group)
+        if end is not None:
+            end.record()
         return out
 
     def all_reduce_sum(self, t):
+        self.calls += 1
+        self.bytes += t.numel() * t.element_size()
+        end = self._bracket(t)
         if self.stage and t.is_cuda:
             h = t.cpu()
             self.dist.all_reduce(h, op=self.dist.ReduceOp.SUM, group=self.group)
             t.copy_(h)
-            return t
-        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
+        else:
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
+        if end is not None:
+            end.record()
         return t
 
 
-def make_comm(group=None):
+def make_comm(group=None, force=False):
+    """The collectives of ``group``: torch.distributed when a process group of more than one rank is up, else the
+    world-of-one stand-in.  ``force`` takes the torch.distributed path for a world of one as well (how the RCCL
+    calls of this module are exercised on a one-GPU box)."""
     import torch.distributed as dist
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
-        return _Dist(group)
+    if dist.is_available() and dist.is_initialized() and (force or dist.get_world_size(group) > 1):
+        return _Dist(group, forced=force)
     return _Solo()
 
 
@@ -93,6 +130,7 @@ def detect_chunk_sharded(engine, ext_frames, a, b, n_frames, comm=None, want_fin
     cluster (n,3); plus this rank's ``final_bits`` for its own frames on request.
     """
     comm = comm or make_comm()
+    exchange = getattr(comm, "exchange", comm.world > 1)
     radius = int(engine.params.sliding_window_radius)
     T = int(engine.params.consecutive_threshold)
     lo, hi = halo_range(n_frames, a, b, radius)
@@ -102,7 +140,7 @@ def detect_chunk_sharded(engine, ext_frames, a, b, n_frames, comm=None, want_fin
     if nown <= 0:
         raise ValueError("every rank needs at least one frame of the chunk")
     edge = max(T - 1, 0)
-    if comm.world > 1 and nown < edge:
+    if exchange and nown < edge:
         raise ValueError("frame-range sharding needs at least consecutive_threshold-1 = %d frames per rank" % edge)
     own = ext_frames[hl:hl + nown]
 
@@ -118,28 +156,30 @@ def detect_chunk_sharded(engine, ext_frames, a, b, n_frames, comm=None, want_fin
     engine.remove_bright_regions(bright, raw, H, W, out=raw)
 
     # persistence across shard boundaries
-    if comm.world > 1 and edge > 0:
+    if exchange and edge > 0:
         mine = torch.cat([raw[:edge], raw[nown - edge:]], dim=0).contiguous()
         edges = comm.all_gather(mine)
         stack[:edge] = edges[comm.rank - 1][edge:] if comm.rank > 0 else 0
         stack[edge + nown:] = edges[comm.rank + 1][:edge] if comm.rank + 1 < comm.world else 0
         pers = engine.persistent_mask(stack, None, H, W)
         pers = engine.or_planes(torch.stack(comm.all_gather(pers)), H, W)
-    elif comm.world > 1:
+    elif exchange:
         pers = engine.persistent_mask(raw, keep, H, W)         # T <= 1: nothing crosses a boundary
         pers = engine.or_planes(torch.stack(comm.all_gather(pers)), H, W)
     else:
         pers = engine.persistent_mask(raw, keep, H, W)
 
     # static map from chunk-wide heat / valid sums
-    maps = comm.all_reduce_sum(engine.static_maps(own, raw, pers, keep))
+    maps = engine.static_maps(own, raw, pers, keep)
+    if exchange:
+        maps = comm.all_reduce_sum(maps)
     static = engine.static_from_maps(maps)
 
     fin, c3 = engine.finalize(own, raw, pers, static, keep, want_bits=True)
     cluster, _ = engine.cluster_stats(own, fin, keep)
 
     # gather the per-frame scalars (padded to the largest shard)
-    if comm.world > 1:
+    if exchange:
         sizes = [shard_range(n_frames, r, comm.world) for r in range(comm.world)]
         mx = max(e - s for s, e in sizes)
         pack = torch.zeros((mx, 10), dtype=torch.int64, device=ext_frames.device)

@@ -93,11 +93,23 @@ int ipx_bgr2gray(ipx_ctx *ctx, const uint8_t *bgr, size_t npix, uint8_t *gray);
 
 /* ---- a3: compute_optical_flow_metric, ip.py:852-873 --------------------------------------
  * flows[0] = 0 (or the metric against prev_frame when given: the left halo of a frame-range
- * shard); flows[i] = mean Farneback flow magnitude between frames i-1 and i, as float32
- * (np.mean of an f32 array).  keep[i] = (double)flows[i] <= flow_threshold (ip.py:559).
- * Frames of 2x2 up to 2^26 pixels (IPX_ERR_UNSUPPORTED beyond: 32-bit buffer offsets). */
+ * shard); flows[i] = mean Farneback flow magnitude between frames i-1 and i, as float32: the f32
+ * magnitudes are added in float64 in a fixed order and the mean is rounded to f32 once.  (The
+ * reference's np.mean of the f32 array, ip.py:868, is numpy's f32 pairwise sum: the two agree
+ * to ~1e-7 relative, inside the 1e-5 of the float metrics, but not bit for bit, so a frame whose
+ * metric lies within ~1e-7 relative of flow_threshold could be kept here and discarded there;
+ * bench.py --motion and tests/test_gpu_configs.py report how close frames come to it.)
+ * keep[i] = (double)flows[i] <= flow_threshold (ip.py:559).
+ * Frames of 2x2 up to 2^26 pixels (IPX_ERR_UNSUPPORTED beyond: 32-bit buffer offsets).
+ * Failure inside the stage's kernels (a bounded wait between its waves running out) is not silent:
+ * every metric of the call is then NaN with keep = 0, ipx_synchronize returns IPX_ERR_HIP and
+ * ipx_flow_status reads (and clears) the condition. */
 int ipx_flow_metric(ipx_ctx *ctx, const uint8_t *frames, int n, int H, int W,
                     const uint8_t *prev_frame, float *flows, uint8_t *keep);
+int ipx_flow_status(ipx_ctx *ctx, int *raised, int clear);     /* synchronises the stream        */
+/* test hook: number of polls after which a wave of flow_iter_kernel gives up waiting for its
+ * partner waves (default 2^27, ~10 s); 0 forces the failure path described above. */
+int ipx_debug_fi_spin_limit(ipx_ctx *ctx, unsigned limit);
 /* One Farneback pair on float32 images, full flow field (H,W,2) out: unit parity of
  * cv2.calcOpticalFlowFarneback(prev,next,None,0.5,3,15,3,5,2.0,0), ip.py:858-867. */
 int ipx_farneback_pair(ipx_ctx *ctx, const float *prev, const float *next, int H, int W, float *flow);

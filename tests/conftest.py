@@ -13,6 +13,10 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # Tests that need a second process on the GPU (multi-video replicas, the RCCL process group) fork it from a
+    # helper that must exist before THIS process initialises the GPU: start it now, while nothing has.
+    from image_processing_amd import multi
+    multi.ensure_launcher()
 
 
 @pytest.fixture(scope="session")

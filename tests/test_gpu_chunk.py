@@ -198,3 +198,40 @@ def test_randomised_parity_sweep(eng):
     assert done >= 140
     for seed in range(7000, 7080):                          # single pairs of any content, field against field
         assert fuzz_parity.flow_case(eng, seed).startswith("ok")
+
+
+def test_flow_handoff_timeout_is_not_silent():
+    """flow_iter_kernel's consumer waves meet on an LDS counter with a bounded wait.  With the bound forced to
+    zero polls (ipx_debug_fi_spin_limit) the wait runs out: the call must then report NaN metrics with keep = 0,
+    ipx_synchronize must fail, detect_chunk must raise, and after clearing the condition the same context must
+    give the right answer again."""
+    import torch
+    from image_processing_amd import _ipx, synth
+    from image_processing_amd.engine import Engine
+    frames = synth.chunk_numpy(3, 9, 120, 300, hot=5.0, stuck=1, motion_at=(4,), shift=5.0)
+    ref = Engine(0)
+    good, good_keep = ref.flow_metric(ref.to_device(frames))
+    good, good_keep = good.cpu().numpy(), good_keep.cpu().numpy()
+    ref.close()
+    eng = Engine(0)
+    try:
+        fr = eng.to_device(frames)
+        _ipx.check(_ipx.lib.ipx_debug_fi_spin_limit(eng._ctx, 0))
+        flows, keep = eng.flow_metric(fr)
+        torch.cuda.synchronize()
+        flows, keep = flows.cpu().numpy(), keep.cpu().numpy()
+        assert flows[0] == 0 and keep[0] == 1                      # frame 0 has no pair
+        assert np.isnan(flows[1:]).all() and not keep[1:].any()
+        with pytest.raises(_ipx.IpxError) as ei:
+            eng.synchronize()
+        assert ei.value.status == -2 and "timed out" in str(ei.value)
+        with pytest.raises(RuntimeError):
+            eng.detect_chunk(fr)
+        assert eng.flow_status(clear=True) is True
+        _ipx.check(_ipx.lib.ipx_debug_fi_spin_limit(eng._ctx, 1 << 27))
+        assert eng.flow_status() is False
+        flows, keep = eng.flow_metric(fr)
+        eng.synchronize()
+        assert np.array_equal(flows.cpu().numpy(), good) and np.array_equal(keep.cpu().numpy(), good_keep)
+    finally:
+        eng.close()

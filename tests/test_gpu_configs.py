@@ -147,3 +147,49 @@ def test_config1_full_chunk_properties(eng):
     for r in range(world):
         for k in ("flows", "keep", "counts", "cluster"):
             assert bool((res[r][k].to(a[k].dtype) == a[k]).all()), (r, k)
+
+
+def test_config4_4k_full_chunk_properties(eng):
+    """configs[4] at full size on one GPU: a 1000-frame chunk of 3840x2160 (the unit each of the 8 GPUs of the
+    multi-video batch processes).  Size-independent properties: bitwise determinism, and frame-range sharding
+    (two shards as threads on this GPU) reproduces the whole-chunk result."""
+    import threading
+    import torch
+    from image_processing_amd import sharding, synth
+    from image_processing_amd.engine import Engine
+    from test_gpu_sharding import ThreadComm
+    dev = torch.device("cuda", 0)
+    n, world = 1000, 2
+    fr = synth.chunk_torch(4, n, 2160, 3840, dev, speeds=[0, 0, 0, 4], segment=25)
+    a = eng.detect_chunk_device(fr)
+    b = eng.detect_chunk_device(fr)
+    for k in ("flows", "keep", "counts", "cluster"):
+        assert bool((a[k] == b[k]).all()), k
+    kept = int(a["keep"].sum())
+    assert 0 < kept < n and int(a["counts"][:, 0].sum()) > 0
+    del b
+    comm = ThreadComm(world)
+    res, errors = [None] * world, []
+
+    def work(rank):
+        try:
+            e = Engine(0)
+            lo_, hi_ = sharding.shard_range(n, rank, world)
+            lo, hi = sharding.halo_range(n, lo_, hi_, int(e.params.sliding_window_radius))
+            out = sharding.detect_chunk_sharded(e, fr[lo:hi], lo_, hi_, n, comm.view(rank))
+            torch.cuda.synchronize()
+            res[rank] = {k: out[k].clone() for k in ("flows", "keep", "counts", "cluster")}
+            e.close()
+        except Exception as ex:                     # noqa: BLE001
+            errors.append(ex)
+            comm.barrier.abort()
+
+    th = [threading.Thread(target=work, args=(r,)) for r in range(world)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(400)
+    assert not errors, errors
+    for r in range(world):
+        for k in ("flows", "keep", "counts", "cluster"):
+            assert bool((res[r][k].to(a[k].dtype) == a[k]).all()), (r, k)

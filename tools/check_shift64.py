@@ -8,8 +8,14 @@ Shift64HighRegBug; hipcc 7.2 does not apply the workaround to gfx950.
 
     python tools/check_shift64.py            compiles every csrc/*.hip to ISA and lists offending kernels (exit 1)
 
-A kernel is cured by allocating one more register: IPX_VGPR_PAD(n) (ipx_internal.h) with n = the kernel's
-next_free_vgpr printed here.
+A kernel is cured by keeping a register allocated that the code does not use, so that the shift amount cannot be
+the allocation's last register: IPX_VGPR_PAD_SAFE() (ipx_internal.h; v62 -> a 64-register allocation whose last
+register the compiler never hands out), or IPX_VGPR_PAD(n) with n = the kernel's next_free_vgpr printed here.
+
+What the characterisation covers and what it does not (measured with tools/hwtest/seg_loop.hip only): the three
+opcodes below with a VGPR shift amount.  NOT tested: shift amounts held in SGPRs or given as constants, the
+64-bit shift folded into v_lshl_add_u64, other allocation granules than 8, and other opcodes that read a 64-bit
+pair next to the allocation's end.  The scan therefore guards the failure that was observed, not a class.
 """
 import os
 import re
@@ -64,10 +70,10 @@ def check_asm(asm_text):
     return bad
 
 
-def compile_to_asm(src, flags):
+def compile_to_asm(src, flags, hipcc="/opt/rocm/bin/hipcc"):
     with tempfile.TemporaryDirectory() as td:
         out = os.path.join(td, "k.s")
-        subprocess.check_call(["/opt/rocm/bin/hipcc"] + flags + ["-S", "--cuda-device-only", "-o", out, src],
+        subprocess.check_call([hipcc] + flags + ["-S", "--cuda-device-only", "-o", out, src],
                               stderr=subprocess.DEVNULL)
         with open(out) as f:
             return f.read()
@@ -79,7 +85,7 @@ def check_library():
     flags = [f for f in b.FLAGS if f not in ("-fPIC",)]
     bad = []
     for s in b.SOURCES:
-        bad += [(s,) + x for x in check_asm(compile_to_asm(os.path.join(b.CSRC, s), flags))]
+        bad += [(s,) + x for x in check_asm(compile_to_asm(os.path.join(b.CSRC, s), flags, b._hipcc()))]   # the build's compiler
     return bad
 
 
