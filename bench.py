@@ -10,16 +10,29 @@ video", processed in the reference's 1000-frame chunks).  N > 1 (launched by tor
 one rank per GPU): configs[2], a chunk of N x 1000 frames is sharded by frame range, 1000 frames per GPU
 (weak scaling), with the persistence / static-map / result exchanges over RCCL inside the step.
 
-Rank 0 prints ONE JSON line.  `roofline` is measured live: libipx's built-in profiler records HIP
-events on the launch stream around every kernel of the timed steps; the dominant kernel class (most
-GPU time) is priced as algorithmic bytes / time against the 8 TB/s HBM peak.  `cpu_baseline` times
-the CPU oracle (oracle/, a port: the reference itself needs cv2 + numba, absent from this image) on
-a bounded sample of the same frames, rank 0, N = 1 only.
+Rank 0 prints ONE JSON line.
+* `value`: K steps timed with the built-in profiler OFF.
+* `roofline`, `kernels`: a SECOND pass of the same steps with libipx's profiler on (HIP events on the launch
+  stream around every kernel); the dominant kernel class (most GPU time) is priced as algorithmic bytes / time
+  against the 8 TB/s HBM peak (`frac`), and as the HBM bytes of the committed PMC passes / time (`frac_hbm`).
+* `cpu_baseline`: the CPU oracle (oracle/, a port: the reference needs cv2 + numba, absent from this image)
+  on a bounded sample of the same frames, rank 0, N = 1 only, with per-stage milliseconds.
+* `config.min_flow_margin`: how close the motion test came to its threshold (the discard list's robustness).
+* `throughput_pinned_host`, `throughput_from_avi` (N = 1, never `value`): the same path with chunks starting in
+  pinned host memory (upload on a side stream under the previous chunk) and in an uncompressed AVI on disk
+  (decode thread + the above), SURVEY section 8(d) figures (ii) and (iii).  --no-modes skips them.
+* N > 1: `collectives`: GPU milliseconds, calls and bytes of the RCCL exchanges per chunk.
+
+Other workloads (never the default): --height/--width/--frames, --motion (configs[3]), and
+--videos V (configs[4]): V synthetic videos of --video-frames frames in uncompressed AVI files, every rank (= GPU
+process) runs the chunk driver image_processing.main on its share (videos rank, rank + N, ...) with overlapped
+decode / upload, no collectives; a step is one pass over all V videos.
 """
 import argparse
 import json
 import os
 import sys
+import tempfile
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -38,12 +51,18 @@ def parse():
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--motion", action="store_true", help="camera-motion-heavy sequence (configs[3])")
     ap.add_argument("--cpu-frames", type=int, default=128, help="frames of the CPU-baseline sample (0 = skip)")
-    ap.add_argument("--no-profile", action="store_true", help="do not record per-kernel events (roofline = null)")
+    ap.add_argument("--no-profile", action="store_true", help="skip the profiled pass (roofline = null)")
+    ap.add_argument("--profile-steps", type=int, default=2, help="steps of the profiled pass")
+    ap.add_argument("--no-modes", action="store_true", help="skip the pinned-host and from-AVI throughput figures")
+    ap.add_argument("--videos", type=int, default=0, help="configs[4]: number of videos of the multi-video batch")
+    ap.add_argument("--video-frames", type=int, default=240, help="frames per video (--videos)")
+    ap.add_argument("--video-chunk", type=int, default=120, help="step_size of the chunk driver (--videos)")
     return ap.parse_args()
 
 
 def load_traffic(kernel, workload):
-    """HBM bytes per launch of `kernel` from the committed PMC passes (profiles/*_traffic.json), or None."""
+    """HBM bytes per launch of `kernel` from the committed PMC passes (profiles/*_traffic.json), or None.
+    The newest file (by name) that names this workload wins."""
     import glob
     best = None
     for p in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json"))):
@@ -57,21 +76,165 @@ def load_traffic(kernel, workload):
     return best
 
 
-def cpu_baseline(frames_np):
-    """The oracle pipeline on the sample, timed on this host's cores (OpenMP inside the C part)."""
-    from oracle import pipeline
-    t0 = time.perf_counter()
-    pipeline.detect_damaged_pixels(frames_np)
-    dt = time.perf_counter() - t0
+def cpu_threads():
     omp = int(os.environ.get("OMP_NUM_THREADS", "0") or 0)
     try:
         avail = len(os.sched_getaffinity(0))
     except Exception:
         avail = os.cpu_count() or 1
-    cores = min(omp, avail) if omp > 0 else avail
+    return min(omp, avail) if omp > 0 else avail
+
+
+def cpu_baseline(frames_np):
+    """The oracle pipeline on the sample, timed on this host's cores (OpenMP inside the C part)."""
+    from oracle import pipeline
+    stages = {}
+    t0 = time.perf_counter()
+    pipeline.detect_damaged_pixels(frames_np, timings=stages)
+    dt = time.perf_counter() - t0
+    threads = cpu_threads()
     n, h, w = frames_np.shape
-    return dict(value=n / dt, unit="frames/s", cores=cores, kind="port",
-                sample="%d frames of the step's first chunk (%dx%d), whole path incl. flow; %.1f s" % (n, w, h, dt))
+    return dict(value=n / dt, unit="frames/s", cores=threads, threads=threads, kind="port",
+                sample="%d frames of the step's first chunk (%dx%d), whole path incl. flow; %.1f s" % (n, w, h, dt),
+                per_stage_ms={k: round(1e3 * v, 1) for k, v in stages.items()},
+                note="the reference's batch script asks for 36 cores (image_processing_script.sh:5); this box gives the "
+                     "job %d, so there is no 36-thread line" % threads)
+
+
+def device_copy_gbs(src):
+    """Measured device-copy ceiling beside the 8 TB/s spec: numel bytes read + numel written per copy."""
+    import torch
+    dst = torch.empty_like(src)
+    dst.copy_(src)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(5):
+        dst.copy_(src)
+    e1.record()
+    torch.cuda.synchronize()
+    return 5 * 2.0 * src.numel() / (e0.elapsed_time(e1) * 1e-3) / 1e9
+
+
+def throughput_modes(chunks_dev, H, W):
+    """SURVEY 8(d) figures (ii) and (iii) for the chunks of the main run; returns two dicts."""
+    import numpy as np
+    import torch
+    import image_processing as ip
+    from image_processing_amd import avi
+    n = chunks_dev[0].shape[0]
+    pinned = []
+    for b in chunks_dev:
+        p = torch.empty(b.shape, dtype=torch.uint8, pin_memory=True)
+        p.copy_(b)
+        pinned.append(p)
+    torch.cuda.synchronize()
+    kw = dict(plot=False, show_plots=False, save_plots=False, output_folder="results", visualise_damaged_pixels_plot=True,
+              plot_damaged_pixels_plot=True, plot_heatmap_plot=True, params=None)
+
+    def run_pinned(count):
+        pending = None
+        for i in range(count):
+            done = ip._submit_chunk(([None] * n, pinned[i % 2]), i, kw)
+            if pending is not None:
+                pending()
+            pending = done
+        pending()
+    run_pinned(1)
+    torch.cuda.synchronize()
+    count = 4
+    t0 = time.perf_counter()
+    run_pinned(count)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    from_pinned = dict(value=round(count * n / dt, 1), unit="frames/s", chunks=count, frames_per_chunk=n,
+                       upload_gbs=round(count * n * H * W / dt / 1e9, 2),
+                       what="chunks start in pinned host memory; upload on a side stream under the previous chunk")
+    # (iii): an uncompressed 8-bit AVI on disk (a RIFF AVI holds 4 GB), read by image_processing.main
+    per = max(2, min(n, int(1.9e9 / (H * W)) // 2))
+    host = [p.numpy() for p in pinned]
+    fd, fn = tempfile.mkstemp(suffix=".avi", prefix="ipx_bench_")
+    os.close(fd)
+    try:
+        avi.write_avi(fn, [host[c % 2][i] for c in range(2) for i in range(per)], fps=25.0)
+        import contextlib
+        import io
+        with contextlib.redirect_stdout(io.StringIO()):
+            t0 = time.perf_counter()
+            res = ip.main(fn, average_time=1.0, max_chunks=None, step_size=per)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+        assert len(res["averages_counts"]) > 0 and np.isfinite(np.nansum(res["averages_counts"]))
+        from_avi = dict(value=round(2 * per / dt, 1), unit="frames/s", chunks=2, frames_per_chunk=per,
+                        what="chunks start in an uncompressed 8-bit AVI (page cache); decode thread + pinned upload; "
+                             "includes the first chunk's decode, which nothing overlaps")
+    finally:
+        os.remove(fn)
+    return from_pinned, from_avi
+
+
+def bench_videos(args, world, rank, dev):
+    """configs[4]: the multi-video batch.  Every rank owns videos rank, rank + N, ...; no collectives on the data path."""
+    import contextlib
+    import io
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    import image_processing as ip
+    from image_processing_amd import avi, synth
+    H, W, M, S = args.height, args.width, args.video_frames, args.video_chunk
+    mine = list(range(rank, args.videos, world))
+    tmp = tempfile.mkdtemp(prefix="ipx_videos_")
+    files = []
+    try:
+        for v in mine:                                     # synthetic footage -> uncompressed AVI (the decode side's input)
+            fr = synth.chunk_torch(4 + v, M, H, W, dev).cpu().numpy()
+            fn = os.path.join(tmp, "video%02d.avi" % v)
+            avi.write_avi(fn, fr, fps=25.0)
+            files.append(fn)
+            del fr
+
+        def one_pass():
+            out = []
+            with contextlib.redirect_stdout(io.StringIO()):
+                for fn in files:
+                    out.append(ip.main(fn, average_time=1.0, max_chunks=None, step_size=S))
+            return out
+
+        def fence():
+            if world > 1:
+                dist.barrier()
+            torch.cuda.synchronize()
+
+        for _ in range(args.warmup):
+            one_pass()
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            res = one_pass()
+        fence()
+        dt = time.perf_counter() - t0
+    finally:
+        for fn in files:
+            if os.path.exists(fn):
+                os.remove(fn)
+        os.rmdir(tmp)
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    if rank == 0:
+        total = args.videos * M * args.steps
+        ok = all(np.isfinite(np.nansum(r["averages_counts"])) for r in res)
+        line = dict(metric="frames/sec (whole node), multi-video batch", value=round(total / dt, 2), unit="frames/s",
+                    n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=round(1e3 * dt / args.steps, 3),
+                    higher_is_better=True, scaling="weak", vs_baseline=None, dtype="u8 (flow metric in f32/f64)",
+                    data="synthetic",
+                    config=dict(workload="%d videos of %dx%d u8, %d frames each in uncompressed AVI files, %d-frame chunks, "
+                                         "one process per GPU, decode + upload overlapped, no collectives" % (args.videos, W, H, M, S),
+                                videos=args.videos, videos_per_gpu=len(mine), results_finite=bool(ok)),
+                    roofline=None, cpu_baseline=None,
+                    note="includes decode from the page cache and the PCIe upload: not roofline-comparable")
+        print(json.dumps(line))
 
 
 def main():
@@ -79,7 +242,7 @@ def main():
     import numpy as np
     import torch
     import torch.distributed as dist
-    from image_processing_amd import sharding, synth
+    from image_processing_amd import hostmath, sharding, synth
     from image_processing_amd.engine import Engine
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -99,6 +262,12 @@ def main():
     assert world == args.gpus, "--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world)
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
+    if args.videos > 0:
+        bench_videos(args, world, rank, dev)
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
     H, W = args.height, args.width
     F = args.frames or 1000                  # the same work per GPU at every N (weak scaling)
     n_total = F * world
@@ -136,14 +305,14 @@ def main():
     def run(first, count):
         """`count` steps, software-pipelined as a chunk driver would: step k+1 is on the GPU while the host
         finishes step k.  Every step's results are produced inside the call."""
-        res, pending = None, None
+        res, pending = [], None
         for i in range(first, first + count):
             nxt = submit(i)
             if pending is not None:
-                res = pending()
+                res.append(pending())
             pending = nxt
         if pending is not None:
-            res = pending()
+            res.append(pending())
         return res
 
     def fence():
@@ -151,38 +320,42 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # ---- pass 1: the timed steps, profiler off ------------------------------------------------------
     run(0, args.warmup)
-    if not args.no_profile:
-        eng.profile_enable(True)
-        eng.profile_reset()
     fence()
     t0 = time.perf_counter()
-    res = run(args.warmup, args.steps)
+    results = run(args.warmup, args.steps)
     fence()
     dt = time.perf_counter() - t0
-    prof = {} if args.no_profile else eng.profile_read()
-    if not args.no_profile:
-        eng.profile_enable(False)
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device="cpu" if rehearse else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
-    copy_gbs = None
+    # ---- pass 2: the same steps with per-kernel events (roofline, kernel table, collective times) -----
+    prof, coll, psteps, dt_prof = {}, None, max(1, args.profile_steps), None
+    if not args.no_profile:
+        eng.profile_enable(True)
+        eng.profile_reset()
+        if world > 1 and hasattr(comm, "timed"):
+            comm.collective_ms()
+            comm.timed = True
+        fence()
+        t1 = time.perf_counter()
+        run(args.warmup, psteps)
+        fence()
+        dt_prof = time.perf_counter() - t1
+        prof = eng.profile_read()
+        eng.profile_enable(False)
+        if world > 1 and hasattr(comm, "timed"):
+            calls, nbytes = comm.calls, comm.bytes
+            ms = comm.collective_ms()
+            comm.timed = False
+            coll = dict(ms_per_chunk=round(ms / psteps, 3), calls_per_chunk=calls // psteps, bytes_per_chunk=nbytes // psteps,
+                        backend="gloo (rehearsal)" if rehearse else "nccl (RCCL)", rank=0)
+
     if rank == 0:
-        # measured device-copy ceiling beside the 8 TB/s spec: 2 GB read + 2 GB written per copy
-        src = chunks[0]
-        dst = torch.empty_like(src)
-        dst.copy_(src)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(5):
-            dst.copy_(src)
-        e1.record()
-        torch.cuda.synchronize()
-        copy_gbs = 5 * 2.0 * src.numel() / (e0.elapsed_time(e1) * 1e-3) / 1e9
-        del dst
-    if rank == 0:
+        copy_gbs = device_copy_gbs(chunks[0])
         workload = "%dx%d u8, %d-frame chunks%s" % (W, H, n_total, ", camera motion" if args.motion else "")
         roof = None
         kernels = {}
@@ -195,24 +368,41 @@ def main():
                                   share=round(v["ms"] / tot_ms, 4))
             dom = max(prof, key=lambda k: prof[k]["ms"])
             v = prof[dom]
-            ach = v["bytes"] / (v["ms"] * 1e-3) / 1e9
+            avg_s = v["ms"] * 1e-3 / v["launches"]
+            ach = v["bytes"] / v["launches"] / avg_s / 1e9
             traffic = load_traffic(dom, workload)
             roof = dict(bound="hbm", kernel=dom, achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit="GB/s",
                         frac=round(ach / HBM_PEAK_GBS, 4), traffic=traffic,
-                        bytes_per_launch=round(v["bytes"] / v["launches"]), avg_launch_us=round(1e3 * v["ms"] / v["launches"], 2),
+                        achieved_hbm=round(traffic / avg_s / 1e9, 1) if traffic else None,
+                        frac_hbm=round(traffic / avg_s / 1e9 / HBM_PEAK_GBS, 4) if traffic else None,
+                        bytes_per_launch=round(v["bytes"] / v["launches"]), avg_launch_us=round(1e6 * avg_s, 2),
                         launches=v["launches"], share_of_gpu_time=round(v["ms"] / tot_ms, 4),
-                        device_copy_gbs=round(copy_gbs, 1))
+                        device_copy_gbs=round(copy_gbs, 1),
+                        measured_in="a separate pass of %d steps with per-kernel HIP events (%.1f ms per step; the timed "
+                                    "steps run without them)" % (psteps, 1e3 * dt_prof / psteps))
         cpu = None
         if world == 1 and args.cpu_frames > 0:
             cpu = cpu_baseline(chunks[args.warmup % 2][:args.cpu_frames].cpu().numpy())
-        kept = int(np.sum(res["keep"]))
+        last = results[-1]
+        kept = int(np.sum(last["keep"]))
+        thr = float(eng.params.flow_threshold)
+        margins = [hostmath.flow_margin(r["flows"], thr) for r in results]
         line = dict(metric="frames/sec (whole node) at 1080p", value=round(n_total * args.steps / dt, 2), unit="frames/s",
                     n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=round(1e3 * dt / args.steps, 3),
                     higher_is_better=True, scaling="weak", vs_baseline=None, dtype="u8 (flow metric in f32/f64)",
                     data="synthetic",
                     config=dict(workload=workload, frames_per_gpu=F, sharding="frame-range x%d" % world if world > 1 else "none",
-                                kept_frames_last_step=kept),
+                                kept_frames_last_step=kept, flow_threshold=thr,
+                                min_flow_margin=round(min(m["min_margin"] for m in margins), 6),
+                                frames_within_1e_3_of_threshold=sum(m["frames_within_rel"] for m in margins)),
                     roofline=roof, cpu_baseline=cpu, kernels=kernels)
+        if coll:
+            line["collectives"] = coll
+        if world == 1 and not args.no_modes:
+            try:
+                line["throughput_pinned_host"], line["throughput_from_avi"] = throughput_modes(chunks, H, W)
+            except Exception as e:                      # noqa: BLE001 - the extra figures never take the line down
+                line["throughput_modes_error"] = repr(e)
         print(json.dumps(line))
     if world > 1:
         dist.barrier()

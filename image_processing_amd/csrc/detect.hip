@@ -5,23 +5,32 @@
 //   get_damaged_pixel_mask               ip.py:635-648  (f32 threshold chain A.2, 30x30 box mean A.3)
 //   (background > brightness_threshold)  ip.py:743      (input of remove_bright_regions)
 //
-// One 256-thread workgroup owns a 64x64 pixel tile of one frame.  The 30x30 window sum is an
-// exact integer: the (64+29)^2 window is staged in LDS, summed horizontally (u16) then
-// vertically (i32).  `frame > S*(1/900.0)` in double is equivalent to `900*frame > S` in
-// integers (S*(1/900.0) == v exactly when S == 900 v, and the next integers are 1/900 away).
-// Mask bits leave the kernel as 64-bit words built by wave64 ballots.
+// One 256-thread workgroup owns a 128 x 64 pixel tile of one frame (128 pixels = one 128-byte line per row of
+// every temporal neighbour).  The 30x30 window sum is an exact integer: the (128+29) x (64+29) window is staged
+// in LDS, summed horizontally (u16) into LDS, and every thread slides the vertical sum down its own 4 columns
+// x 8 rows in registers.  `frame > S*(1/900.0)` in double is equivalent to `900*frame > S` in integers
+// (S*(1/900.0) == v exactly when S == 900 v, and the next integers are 1/900 away).  Mask bits leave the kernel
+// as 64-bit words assembled from per-thread nibbles.
 //
-// Floating-point contract (must stay bit-exact with the reference): no FMA contraction, IEEE
-// f32 divide, IEEE f64 divide/sqrt -- the library is built with -ffp-contract=off and without
-// fast-math.
+// Workgroups are numbered so that an XCD (its own 4 MiB L2; ids are dealt round-robin) owns a fixed eighth of
+// the frame's tiles for ALL frames and walks them frame by frame: the six neighbour frames a tile reads were
+// fetched into that L2 when they were centre / neighbour of the frames just before, so every frame byte
+// crosses the fabric about once instead of seven times.
+//
+// Floating-point contract (must stay bit-exact with the reference): no FMA contraction, IEEE f32 divide, IEEE
+// f64 divide/sqrt -- the library is built with -ffp-contract=off and without fast-math.  The outlier cut of
+// _find_background is DECIDED in integers wherever that is provably the reference's decision (background_px),
+// and by the reference's float chain (background_px_chain) in the rare cases where it is not.
 #include "ipx_internal.h"
 
 namespace {
 
-constexpr int TW = 64, TH = 64, KS = 30, AX = 15;
+constexpr int TW = 128, TH = 64, KS = 30, AX = 15;
 constexpr int WIN_H = TH + KS - 1;       // 93 rows
-constexpr int WIN_STRIDE = 100;          // bytes per staged row: 96 used (x0-16 .. x0+79), padded
-constexpr int HS_STRIDE = 64;            // u16 per row
+constexpr int WIN_W = TW + 32;           // staged columns x0-16 .. x0+143 (16-byte aligned on both sides)
+constexpr int WIN_STRIDE = WIN_W + 16;   // bytes per staged row (176: 16-byte aligned, 44 dwords: rows 12 banks apart)
+constexpr int HS_STRIDE = TW;            // u16 per row of horizontal sums
+constexpr int RG = 8;                    // rows per thread in the per-pixel phase (4 columns x 8 rows)
 
 __device__ __forceinline__ int reflect101(int p, int len)
 {
@@ -57,24 +66,22 @@ __device__ __forceinline__ double div_by(double a, double b, double y)
     return __builtin_fma(r, y, q);
 }
 
-// _find_background for one pixel from its n temporal neighbours (byte j of v[0..n)); rcp[i] = 1.0 / i.
-// FULL: n == MAXN is known at compile time (every frame that is 'radius' away from both chunk ends), so the
-// neighbour loops carry no predication.
-template <int MAXN, bool FULL>
-__device__ __forceinline__ float background_px(const uint32_t (&v)[MAXN], int n, int j, double coeff, const double *rcp)
+// _find_background for one pixel, the reference's own float chain: n temporal neighbours
+// b[0..n), rcp[i] = 1.0 / i.  Only reached for the pixels background_px cannot decide in integers.
+template <int MAXN>
+__device__ __forceinline__ float background_px_chain(const int (&b)[MAXN], int n, double coeff, const double *rcp)
 {
-    if (FULL) n = MAXN;
-    const double yn = FULL ? 1.0 / (double)MAXN : rcp[n];
+    const double yn = rcp[n];
     int S = 0;
 #pragma unroll
     for (int k = 0; k < MAXN; ++k)
-        if (FULL || k < n) S += (v[k] >> (8 * j)) & 0xff;
+        if (k < n) S += b[k];
     const float mean = (float)((double)S * yn);  // == (float)S / (float)n == f32(f64(S)/n)
     double acc = 0.0;
 #pragma unroll
     for (int k = 0; k < MAXN; ++k)
-        if (FULL || k < n) {
-            const float diff = (float)((v[k] >> (8 * j)) & 0xff) - mean;
+        if (k < n) {
+            const float diff = (float)b[k] - mean;
             const float d2 = diff * diff;
             acc += (double)d2;
         }
@@ -85,16 +92,90 @@ __device__ __forceinline__ float background_px(const uint32_t (&v)[MAXN], int n,
     int Si = 0, c = 0;
 #pragma unroll
     for (int k = 0; k < MAXN; ++k)
-        if (FULL || k < n) {
-            const int b = (v[k] >> (8 * j)) & 0xff;
-            if (b <= T) { Si += b; ++c; }
-        }
+        if (k < n && b[k] <= T) { Si += b[k]; ++c; }
     return c > 0 ? (float)((double)Si * rcp[c]) : mean;
 }
 
+// Per-workgroup constants of the integer decision below.
+struct BgConst {
+    int n;            // neighbours of this frame (centre excluded)
+    int nodd;         // odd part of n: S/n is a dyadic rational (exact in f32) iff nodd divides S
+    unsigned magic;   // ceil(2^16 / nodd): floor(S / nodd) == (S * magic) >> 16 for S < 4096, nodd <= 15
+    bool unit_coeff;  // pixel_std_coeff == 1.0 (the reference's default, ip.py:204)
+};
+
+// Correctly rounded f32 quotient a / b for an integer-valued a and a small integer b, y = RN32(1 / b): one
+// residual correction of q = RN32(a y) (the residual a - b q is exact in an fma).  Exact over the whole domain
+// this kernel uses it on -- every Si / c with c <= 16, Si <= 255 c, and every such quotient divided by 255 --
+// which tests/test_abi_and_host.py walks through.
+__device__ __forceinline__ float div_small(float a, float b, float y)
+{
+    const float q = a * y;
+    const float r = __builtin_fmaf(-b, q, a);
+    return __builtin_fmaf(r, y, q);
+}
+
+// _find_background for one pixel.  The reference keeps neighbour b iff  b <= mean32 + sd32  (coeff 1; the f64
+// sum of the two f32 values is exact).  With S = sum b, Q = sum b^2, D = n Q - S^2 (= n^2 variance) and
+// t = n b - S (= n (b - mean)) that is, in exact arithmetic,  t <= 0  or  t^2 <= D:  integers below 2^24.  The
+// reference's roundings move the two sides only slightly: mean32 is off by <= 2^-17, so n (b - mean32) = t (1 + r)
+// with |r| <= 2^-17 n / t; and sd32^2 = (D / n^2 + e^2)(1 + h) with e <= 2^-17, |h| <= 5 * 2^-24 (+2^-50) from the
+// three f32 roundings of the squares' path, the f32 rounding of sd and the f64 division and root.  Hence
+//    reference keeps b   if  t^2 + 2^-16 n t + 2^-21.5 D <= D,      drops b  if  t^2 - 2^-16 n t > D + 2^-21.5 D + 2^-26
+// and with t <= 255 n, D <= n^2 255^2 / 4 the slack terms sum to < 0.35 for n <= 6 and < 2.45 for n <= 16:
+// |t^2 - D| >= M (M = 1 resp. 3) decides exactly as the reference does; t <= 0 always keeps (sd32 > 2^-17 when
+// D >= 1, and D = 0 means all values equal).  A tie t^2 == D is the reference's too when S / n is dyadic: then
+// mean32, every difference, every square (<= 24 bits), their sum, sum / n = (t / n)^2 and its root t / n are all
+// exact and mean32 + sd32 == b: kept.  What is left (a tie with an inexact mean, |t^2 - D| < M for n > 6, any
+// coeff other than 1) goes through the reference's float chain.  tools/fuzz_stages.py and the parity sweeps of
+// tests/test_gpu_stages.py compare the result with the oracle's chain.
+//
+// Written as arithmetic on 24-bit integers (no boolean network: one multiply-add, one max, one multiply-add, one
+// shift, one multiply-add, one add and one min per neighbour).
+template <int MAXN, bool FULL>
+__device__ __forceinline__ float background_px(const uint32_t (&v)[MAXN], int j, const BgConst &bc, double coeff,
+                                               const double *rcp, const float *rcpf)
+{
+    const int n = FULL ? MAXN : bc.n;
+    int b[MAXN];
+    int S = 0, Q = 0;
+#pragma unroll
+    for (int k = 0; k < MAXN; ++k) {
+        b[k] = (int)__builtin_amdgcn_ubfe(v[k], 8 * j, 8);     // slots k >= n hold 0
+        S += b[k];
+        Q = __umul24(b[k], b[k]) + Q;
+    }
+    const int D1 = __mul24(n, Q) - __mul24(S, S) + 1;     // D + 1
+    int Si = 0, c = 0;
+    unsigned z = ~0u;                                            // becomes 0 when some kept neighbour ties (u^2 == D)
+    bool hard = false;
+#pragma unroll
+    for (int k = 0; k < MAXN; ++k) {
+        if (FULL || k < n) {                                    // workgroup-uniform
+            const int t = __mul24(n, b[k]) - S;
+            const int u = max(t, 0);
+            const int w = __mul24(u, u) - D1;  // w < 0  <=>  u^2 <= D
+            const unsigned m = (unsigned)w >> 31;
+            Si = __umul24(b[k], m) + Si;
+            c += m;
+            z = min(z, ~(unsigned)w);
+            if (MAXN > 6) hard |= t > 0 && (unsigned)(w + 3) <= 4u && w != -1;   // 0 < |u^2 - D| < 3
+        }
+    }
+    if (z == 0) {                                                // a tie: exact only when S / n is dyadic
+        const int q = (int)(((unsigned)S * bc.magic) >> 16);
+        hard |= S - q * bc.nodd != 0;
+    }
+    hard |= !bc.unit_coeff;
+    if (__builtin_expect(hard, 0)) return background_px_chain<MAXN>(b, n, coeff, rcp);
+    return div_small((float)Si, (float)c, rcpf[c]);             // c >= 1: the smallest neighbour has t <= 0
+}
+
+// ip.py:638: 30 + (bg / 255) * 225, three separately rounded f32 operations, then maximum(30, .).  bg is a
+// quotient Si / c (see div_small for why the division below is the IEEE one on that domain).
 __device__ __forceinline__ float damage_threshold_f32(float bg)
 {
-    float t = (float)((double)bg * (1.0 / 255.0));   // == bg / 255.0f; three separately rounded f32 ops, ip.py:638
+    float t = div_small(bg, 255.0f, 1.0f / 255.0f);
     t = t * 225.0f;
     t = 30.0f + t;
     return fmaxf(30.0f, t);
@@ -107,70 +188,98 @@ struct DetectArgs {
     uint64_t *bright_bits;   // [count][H*wpr]
     unsigned long long *dense;  // [count][2] or null
     float *bg_out;           // optional (H,W) f32 for the stage entry point (count == 1)
-    int n, H, W, first, radius;
+    int n, H, W, first, radius, count;
+    int tiles_x, tiles_y, per_xcd;   // tiles of a frame and how many of them one XCD owns
     int frame_gt, est_lt;
     float bg_gt;
     double coeff;
 };
 
+// 16 nibbles held one per byte (four dwords) -> 64 bits, nibble k at bits 4k..4k+3
+__device__ __forceinline__ uint32_t nibbles4(uint32_t d)
+{
+    d = (d | (d >> 4)) & 0x00ff00ffu;
+    return (d | (d >> 8)) & 0xffffu;
+}
+
 template <int MAXN>
 __global__ __launch_bounds__(256) void detect_kernel(DetectArgs a)
 {
     __shared__ __attribute__((aligned(16))) uint8_t s_win[WIN_H * WIN_STRIDE];
-    __shared__ __attribute__((aligned(16))) uint16_t s_hs[WIN_H * HS_STRIDE];   // later: flag bytes
-    __shared__ __attribute__((aligned(16))) int32_t s_vs[TH * TW];
+    __shared__ __attribute__((aligned(16))) uint16_t s_hs[WIN_H * HS_STRIDE];
+    __shared__ __attribute__((aligned(16))) uint8_t s_nib[2][TH][TW / 4];      // damaged / bright nibbles per 4 pixels
     __shared__ unsigned int s_cnt[2];
     __shared__ double s_rcp[MAXN + 1];
+    __shared__ float s_rcpf[MAXN + 1];
 
     const int tid = threadIdx.x;
     const int H = a.H, W = a.W;
     const int wpr = (W + 63) >> 6;
-    const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;
-    const int fz = blockIdx.z;              // plane within this call
+    // XCD-aware numbering: XCD x (= id % 8) owns tiles [x * per_xcd, (x+1) * per_xcd) of every frame and takes
+    // them frame by frame.
+    const int xcd = blockIdx.x & 7, k = blockIdx.x >> 3;
+    const int fz = k / a.per_xcd;                                // plane within this call
+    const int tile = xcd * a.per_xcd + (k - fz * a.per_xcd);
+    if (fz >= a.count || tile >= a.tiles_x * a.tiles_y) return;
+    const int tby = tile / a.tiles_x, tbx = tile - tby * a.tiles_x;
+    const int x0 = tbx * TW, y0 = tby * TH;
     const int fi = a.first + fz;            // frame within the chunk
     uint64_t *rawp = a.raw_bits + (size_t)fz * H * wpr;
     uint64_t *brp = a.bright_bits ? a.bright_bits + (size_t)fz * H * wpr : nullptr;
 
-    if (a.keep && !a.keep[fi]) {            // discarded frame: zero planes (wave-uniform exit)
-        if (tid < TH && y0 + tid < H) {
-            rawp[(size_t)(y0 + tid) * wpr + blockIdx.x] = 0;
-            if (brp) brp[(size_t)(y0 + tid) * wpr + blockIdx.x] = 0;
+    if (a.keep && !a.keep[fi]) {            // discarded frame: zero planes (workgroup-uniform exit)
+        if (tid < 2 * TH) {
+            const int ty = tid >> 1, wk = 2 * tbx + (tid & 1);
+            if (y0 + ty < H && wk < wpr) {
+                rawp[(size_t)(y0 + ty) * wpr + wk] = 0;
+                if (brp) brp[(size_t)(y0 + ty) * wpr + wk] = 0;
+            }
         }
         return;
     }
     if (tid < 2) s_cnt[tid] = 0;
-    if (tid <= MAXN) s_rcp[tid] = tid ? 1.0 / (double)tid : 0.0;
+    if (tid <= MAXN) { s_rcp[tid] = tid ? 1.0 / (double)tid : 0.0; s_rcpf[tid] = tid ? 1.0f / (float)tid : 0.0f; }
 
     const uint8_t *frame = a.frames + (size_t)fi * H * W;
     const bool aligned = (W & 3) == 0;
 
-    // ---- phase A: stage the reflected window, columns x0-16 .. x0+79 ------------------------
-    const bool interior_x = aligned && x0 - 16 >= 0 && x0 + 80 <= W;
-    for (int idx = tid; idx < WIN_H * 24; idx += 256) {
-        const int r = idx / 24, q = idx - r * 24;
-        const int gy = reflect101(y0 - AX + r, H);
-        const uint8_t *row = frame + (size_t)gy * W;
-        uint32_t v;
-        if (interior_x) {
-            v = *reinterpret_cast<const uint32_t *>(row + x0 - 16 + 4 * q);
-        } else {
-            v = 0;
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                v |= (uint32_t)row[reflect101(x0 - 16 + 4 * q + j, W)] << (8 * j);
+    // ---- phase A: stage the reflected window, columns x0-16 .. x0+143 ------------------------
+    const bool interior = x0 - 16 >= 0 && x0 + TW + 16 <= W && y0 - AX >= 0 && y0 - AX + WIN_H <= H;
+    if (interior && (W & 15) == 0 && (reinterpret_cast<uintptr_t>(a.frames) & 15) == 0) {
+        const uint8_t *base = frame + (size_t)(y0 - AX) * W + x0 - 16;
+        for (int idx = tid; idx < WIN_H * (WIN_W / 16); idx += 256) {
+            const int r = idx / (WIN_W / 16), q = idx - r * (WIN_W / 16);
+            const uint4 v = *reinterpret_cast<const uint4 *>(base + (size_t)r * W + 16 * q);
+            *reinterpret_cast<uint4 *>(s_win + r * WIN_STRIDE + 16 * q) = v;
         }
-        *reinterpret_cast<uint32_t *>(s_win + r * WIN_STRIDE + 4 * q) = v;
+    } else {
+        const bool interior_x = aligned && x0 - 16 >= 0 && x0 + TW + 16 <= W;
+        for (int idx = tid; idx < WIN_H * (WIN_W / 4); idx += 256) {
+            const int r = idx / (WIN_W / 4), q = idx - r * (WIN_W / 4);
+            const int gy = reflect101(y0 - AX + r, H);
+            const uint8_t *row = frame + (size_t)gy * W;
+            uint32_t v;
+            if (interior_x) {
+                v = *reinterpret_cast<const uint32_t *>(row + x0 - 16 + 4 * q);
+            } else {
+                v = 0;
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    v |= (uint32_t)row[reflect101(x0 - 16 + 4 * q + j, W)] << (8 * j);
+            }
+            *reinterpret_cast<uint32_t *>(s_win + r * WIN_STRIDE + 4 * q) = v;
+        }
     }
     __syncthreads();
 
     // ---- phase B: horizontal 30-sums, hs[r][x] = sum_{i<30} win[r][x+1+i] ---------------------
-    for (int item = tid; item < WIN_H * 4; item += 256) {
-        const int r = item >> 2, seg = item & 3;
+    for (int item = tid; item < WIN_H * (TW / 16); item += 256) {
+        const int r = item >> 3, seg = item & 7;
         const uint32_t *rp = reinterpret_cast<const uint32_t *>(s_win + r * WIN_STRIDE) + seg * 4;
         uint32_t d[12];
 #pragma unroll
         for (int j = 0; j < 12; ++j) d[j] = rp[j];
-        auto byte_at = [&](int k) -> int { return (d[k >> 2] >> (8 * (k & 3))) & 0xff; };
+        auto byte_at = [&](int q) -> int { return (d[q >> 2] >> (8 * (q & 3))) & 0xff; };
         int s = 0;
 #pragma unroll
         for (int i = 1; i <= 30; ++i) s += byte_at(i);
@@ -188,61 +297,77 @@ __global__ __launch_bounds__(256) void detect_kernel(DetectArgs a)
     }
     __syncthreads();
 
-    // ---- phase C: vertical 30-sums, vs[y][x] = sum_{i<30} hs[y+i][x] --------------------------
-    {
-        const int x = tid & 63, q = tid >> 6;
-        int s = 0;
-#pragma unroll 6
-        for (int i = 0; i < 30; ++i) s += s_hs[(16 * q + i) * HS_STRIDE + x];
-        s_vs[(16 * q) * TW + x] = s;
-#pragma unroll 5
-        for (int t = 1; t < 16; ++t) {
-            s += (int)s_hs[(16 * q + 29 + t) * HS_STRIDE + x] - (int)s_hs[(16 * q + t - 1) * HS_STRIDE + x];
-            s_vs[(16 * q + t) * TW + x] = s;
-        }
-    }
-    __syncthreads();
-
-    // ---- phase D: per-pixel tests, 4 pixels per thread, 16 rows per step ---------------------
-    uint8_t *s_flag = reinterpret_cast<uint8_t *>(s_hs);   // [2][TH][TW] bytes: damaged, bright
+    // ---- phase C: per-pixel tests; a thread owns columns 4*cg .. 4*cg+3 of rows 8*rg .. 8*rg+7 and slides the
+    // vertical 30-sum of its columns down those rows in registers ---------------------------------------------
     const int lo = max(0, fi - a.radius), hi = min(a.n, fi + a.radius + 1);
     const int nn = hi - lo - 1;                              // neighbours (centre excluded)
-    const int xq = (tid & 15) * 4;
+    const int cpos = fi - lo;                                // centre's slot in the window
     const bool full = nn == MAXN;                            // workgroup-uniform
+    BgConst bc;
+    bc.n = nn;
+    bc.nodd = nn > 0 ? nn >> __builtin_ctz(nn) : 1;
+    bc.magic = (65536u + bc.nodd - 1) / bc.nodd;
+    bc.unit_coeff = a.coeff == 1.0;
+    const int cg = tid & 31, rg = tid >> 5;
+    const int gx = x0 + 4 * cg;
     unsigned int c_lt = 0, c_gt = 0;
-#pragma unroll 1
-    for (int step = 0; step < 4; ++step) {
-        const int ty = (tid >> 4) + 16 * step;
-        const int gy = y0 + ty, gx = x0 + xq;
-        uint32_t dm = 0, bm = 0;
-        if (gy < H && gx < W) {
-            uint32_t v[MAXN];
-            const int cpos = fi - lo;                       // centre's slot in the window
+    const bool col_live = gx < W;
+    int vs[4] = {0, 0, 0, 0};
+    {
+        const uint16_t *hp = s_hs + (RG * rg) * HS_STRIDE + 4 * cg;
+#pragma unroll 6
+        for (int i = 0; i < KS; ++i) {
+            const uint2 h = *reinterpret_cast<const uint2 *>(hp + i * HS_STRIDE);
+            vs[0] += h.x & 0xffff; vs[1] += h.x >> 16; vs[2] += h.y & 0xffff; vs[3] += h.y >> 16;
+        }
+    }
+    // neighbour frames of one row: slot s holds frame lo + s (+1 from the centre on)
+    auto load_row = [&](int gy, uint32_t (&v)[MAXN]) {
 #pragma unroll
-            for (int s = 0; s < MAXN; ++s) {
-                const int f = lo + s + (s >= cpos ? 1 : 0);
-                v[s] = s < nn ? load4(a.frames + ((size_t)f * H + gy) * W, gx, W, aligned) : 0u;
-            }
-            const uint32_t cen = *reinterpret_cast<const uint32_t *>(s_win + (ty + AX) * WIN_STRIDE + 16 + xq);
-            const int4 vs4 = *reinterpret_cast<const int4 *>(s_vs + ty * TW + xq);
-            const int vs[4] = {vs4.x, vs4.y, vs4.z, vs4.w};
+        for (int s = 0; s < MAXN; ++s) {
+            const int f = lo + s + (s >= cpos ? 1 : 0);
+            v[s] = (s < nn && col_live && gy < H) ? load4(a.frames + ((size_t)f * H + gy) * W, gx, W, aligned) : 0u;
+        }
+    };
+    uint32_t vnext[MAXN];
+    load_row(y0 + RG * rg, vnext);
+#pragma unroll 1
+    for (int r = 0; r < RG; ++r) {
+        const int ty = RG * rg + r;
+        const int gy = y0 + ty;
+        uint32_t v[MAXN];
+#pragma unroll
+        for (int s = 0; s < MAXN; ++s) v[s] = vnext[s];
+        if (r + 1 < RG) load_row(gy + 1, vnext);             // in flight under this row's arithmetic
+        uint32_t dm = 0, bm = 0;
+        if (gy < H && col_live) {
+            const uint32_t cen = *reinterpret_cast<const uint32_t *>(s_win + (ty + AX) * WIN_STRIDE + 16 + 4 * cg);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 if (gx + j < W) {
                     const int pix = (cen >> (8 * j)) & 0xff;
-                    const float bg = full ? background_px<MAXN, true>(v, nn, j, a.coeff, s_rcp) : background_px<MAXN, false>(v, nn, j, a.coeff, s_rcp);
+                    const float bg = full ? background_px<MAXN, true>(v, j, bc, a.coeff, s_rcp, s_rcpf)
+                                          : background_px<MAXN, false>(v, j, bc, a.coeff, s_rcp, s_rcpf);
                     if (a.bg_out) a.bg_out[(size_t)gy * W + gx + j] = bg;
                     const float thr = damage_threshold_f32(bg);
                     const bool dmg = ((float)pix > thr) && (900 * pix > vs[j]);
-                    dm |= (uint32_t)dmg << (8 * j);
-                    bm |= (uint32_t)(bg > a.bg_gt) << (8 * j);
+                    dm |= (uint32_t)dmg << j;
+                    bm |= (uint32_t)(bg > a.bg_gt) << j;
                     c_lt += pix < a.est_lt;
                     c_gt += pix > a.frame_gt;
                 }
             }
         }
-        *reinterpret_cast<uint32_t *>(s_flag + ty * TW + xq) = dm;
-        *reinterpret_cast<uint32_t *>(s_flag + TH * TW + ty * TW + xq) = bm;
+        s_nib[0][ty][cg] = (uint8_t)dm;
+        s_nib[1][ty][cg] = (uint8_t)bm;
+        if (r + 1 < RG) {                                    // slide the window one row down
+            const uint2 hin = *reinterpret_cast<const uint2 *>(s_hs + (ty + KS) * HS_STRIDE + 4 * cg);
+            const uint2 hout = *reinterpret_cast<const uint2 *>(s_hs + ty * HS_STRIDE + 4 * cg);
+            vs[0] += (int)(hin.x & 0xffff) - (int)(hout.x & 0xffff);
+            vs[1] += (int)(hin.x >> 16) - (int)(hout.x >> 16);
+            vs[2] += (int)(hin.y & 0xffff) - (int)(hout.y & 0xffff);
+            vs[3] += (int)(hin.y >> 16) - (int)(hout.y >> 16);
+        }
     }
     if (a.dense) {
         // wave-level reduce, then one LDS atomic per wave
@@ -254,19 +379,15 @@ __global__ __launch_bounds__(256) void detect_kernel(DetectArgs a)
     }
     __syncthreads();
 
-    // ---- phase E: ballot-pack 64 rows x 64 columns into one word per row ----------------------
+    // ---- phase D: 16 nibbles -> one 64-bit word; thread = (plane, row, word of the tile) -------------------
     {
-        const int lane = tid & 63, wv = tid >> 6;
-#pragma unroll 4
-        for (int i = 0; i < 16; ++i) {
-            const int ty = wv * 16 + i;
-            const unsigned long long wd = __ballot(s_flag[ty * TW + lane] != 0);
-            const unsigned long long wb = __ballot(s_flag[TH * TW + ty * TW + lane] != 0);
-            if (lane == 0 && y0 + ty < H) {
-                rawp[(size_t)(y0 + ty) * wpr + blockIdx.x] = wd;
-                if (brp) brp[(size_t)(y0 + ty) * wpr + blockIdx.x] = wb;
-            }
-        }
+        const int plane = tid >> 7, ty = (tid >> 1) & (TH - 1), half = tid & 1;
+        const uint4 q = *reinterpret_cast<const uint4 *>(&s_nib[plane][ty][16 * half]);
+        const uint64_t word = (uint64_t)(nibbles4(q.x) | (nibbles4(q.y) << 16)) |
+                              ((uint64_t)(nibbles4(q.z) | (nibbles4(q.w) << 16)) << 32);
+        const int wk = 2 * tbx + half;
+        uint64_t *dst = plane ? brp : rawp;
+        if (dst && y0 + ty < H && wk < wpr) dst[(size_t)(y0 + ty) * wpr + wk] = word;
     }
     if (a.dense && tid < 2) atomicAdd(&a.dense[(size_t)fz * 2 + tid], (unsigned long long)s_cnt[tid]);
 }
@@ -302,11 +423,18 @@ static int launch_detect(ipx_ctx *ctx, const uint8_t *frames, int n, int H, int 
     DetectArgs a;
     a.frames = frames; a.keep = keep; a.raw_bits = raw_bits; a.bright_bits = bright_bits;
     a.dense = reinterpret_cast<unsigned long long *>(dense_counts); a.bg_out = bg_out;
-    a.n = n; a.H = H; a.W = W; a.first = first; a.radius = ctx->p.sliding_window_radius;
+    a.n = n; a.H = H; a.W = W; a.first = first; a.radius = ctx->p.sliding_window_radius; a.count = count;
+    a.tiles_x = (W + TW - 1) / TW; a.tiles_y = (H + TH - 1) / TH;
+    a.per_xcd = (a.tiles_x * a.tiles_y + 7) / 8;
     a.frame_gt = d.frame_gt; a.est_lt = d.est_lt; a.bg_gt = d.bg_gt; a.coeff = ctx->p.pixel_std_coeff;
     if (dense_counts)
         IPX_CHECK_HIP(hipMemsetAsync(dense_counts, 0, sizeof(int64_t) * 2 * (size_t)count, ctx->stream));
-    dim3 grid((W + TW - 1) / TW, (H + TH - 1) / TH, count), block(256);
+    const size_t blocks = (size_t)8 * a.per_xcd * count;
+    if (blocks > 0x7fffffffu) {
+        ipx_set_error("ipx_detect_raw: %d planes of %d x %d are too many workgroups for one launch", count, W, H);
+        return IPX_ERR_UNSUPPORTED;
+    }
+    dim3 grid((unsigned)blocks), block(256);
     const int r = ctx->p.sliding_window_radius;
     // algorithmic bytes: centre frame + its temporal neighbours read once, two bit-planes written
     double ab = 2.0 * count * H * ipx_wpr(W) * 8;

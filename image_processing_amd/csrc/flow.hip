@@ -1188,18 +1188,21 @@ int run_pairs(ipx_ctx *ctx, const uint8_t *frames, const uint8_t *extra, int fir
         for (int it = 0; it < 3; ++it) {                            // ip.py:864 iterations=3
             a.flow_in = cur; a.flow_out = other;
             const bool reduce = !uv_out && k == 0 && it == 2;
-            double bytes = 40.0 * P + (reduce ? 0.0 : 8.0 * P);
+            // algorithmic bytes of the launch: every array once.  The np pairs of a batch share their
+            // expansions (frame p+1 is the second frame of pair p and the first of pair p+1): np + 1 expansions of
+            // 20 bytes per pixel, not 2 np; per pair the flow written (8) and the flow read (8, or the coarser field).
+            double bytes = 20.0 * P * (np + 1) + (reduce ? 0.0 : 8.0 * P * np);
             if (it > 0) {
-                bytes += 8.0 * P;
-                if (reduce) IPX_LAUNCH_LDS(ctx, KID_FLOW_ITER, bytes * np, FI_LDS_BYTES, (flow_iter_kernel<0, true>), fgrid, fblock, a);
-                else IPX_LAUNCH_LDS(ctx, KID_FLOW_ITER, bytes * np, FI_LDS_BYTES, (flow_iter_kernel<0, false>), fgrid, fblock, a);
+                bytes += 8.0 * P * np;
+                if (reduce) IPX_LAUNCH_LDS(ctx, KID_FLOW_ITER, bytes, FI_LDS_BYTES, (flow_iter_kernel<0, true>), fgrid, fblock, a);
+                else IPX_LAUNCH_LDS(ctx, KID_FLOW_ITER, bytes, FI_LDS_BYTES, (flow_iter_kernel<0, false>), fgrid, fblock, a);
             } else if (k == pl->levels) {
-                IPX_LAUNCH_LDS(ctx, KID_FLOW_ITER, bytes * np, FI_LDS_BYTES, (flow_iter_kernel<1, false>), fgrid, fblock, a);
+                IPX_LAUNCH_LDS(ctx, KID_FLOW_ITER, bytes, FI_LDS_BYTES, (flow_iter_kernel<1, false>), fgrid, fblock, a);
             } else {
                 const LevelGeom &c = pl->lv[k + 1];
                 a.sh = c.lh; a.sw = c.lw; a.x_ofs = g.ux_ofs; a.x_a = g.ux_a; a.y_ofs = g.uy_ofs; a.y_b = g.uy_b;
-                bytes += 8.0 * c.lh * c.lw;
-                IPX_LAUNCH_LDS(ctx, KID_FLOW_ITER, bytes * np, FI_LDS_BYTES, (flow_iter_kernel<2, false>), fgrid, fblock, a);
+                bytes += 8.0 * c.lh * c.lw * np;
+                IPX_LAUNCH_LDS(ctx, KID_FLOW_ITER, bytes, FI_LDS_BYTES, (flow_iter_kernel<2, false>), fgrid, fblock, a);
             }
             float2 *t = cur; cur = other; other = t;
         }

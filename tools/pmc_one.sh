@@ -6,7 +6,7 @@ root=$(pwd); out=$root/gpurun_out
 export TMPDIR=/tmp
 cd /tmp
 timeout -s KILL 400 rocprofv3 --pmc ${ctr//,/ } --output-format csv -d $out/${tag}_pmc -o ${tag} -- \
-    python3 $root/bench.py --steps 1 --warmup 0 --cpu-frames 0 --no-profile > $out/${tag}_pmc.log 2>&1
+    python3 $root/bench.py --steps 1 --warmup 0 --cpu-frames 0 --no-profile --no-modes > $out/${tag}_pmc.log 2>&1
 cd $root
 python3 - "$out/${tag}_pmc/${tag}_counter_collection.csv" <<'PY'
 import csv, sys, collections
