@@ -132,9 +132,73 @@ __device__ __forceinline__ float div_small(float a, float b, float y)
 //
 // Written as arithmetic on 24-bit integers (no boolean network: one multiply-add, one max, one multiply-add, one
 // shift, one multiply-add, one add and one min per neighbour).
+// 24-bit multiply-adds, forced: the compiler otherwise proves the ranges only sometimes and falls back to the
+// quarter-rate 32/64-bit multiplier.  Every operand below is within +-2^23 by construction (bytes, n <= 16,
+// S <= 4080, Q <= 16 * 255^2, t <= 4080).
+__device__ __forceinline__ int mad_i24(int a, int b, int c)
+{
+    int r;
+    asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+__device__ __forceinline__ unsigned mad_u24(unsigned a, unsigned b, unsigned c)
+{
+    unsigned r;
+    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+
+struct BgSums { unsigned Si, c; bool hard; };
+
+// s + byte K of d / s - byte K of d in one instruction (sub-dword operand select)
+template <int K>
+__device__ __forceinline__ int add_byte(int s, uint32_t d)
+{
+    int r;
+    if (K == 0) asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(r) : "v"(s), "v"(d));
+    else if (K == 1) asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(r) : "v"(s), "v"(d));
+    else if (K == 2) asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "=v"(r) : "v"(s), "v"(d));
+    else asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3" : "=v"(r) : "v"(s), "v"(d));
+    return r;
+}
+template <int K>
+__device__ __forceinline__ int sub_byte(int s, uint32_t d)
+{
+    int r;
+    if (K == 0) asm("v_sub_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(r) : "v"(s), "v"(d));
+    else if (K == 1) asm("v_sub_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(r) : "v"(s), "v"(d));
+    else if (K == 2) asm("v_sub_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "=v"(r) : "v"(s), "v"(d));
+    else asm("v_sub_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3" : "=v"(r) : "v"(s), "v"(d));
+    return r;
+}
+
+// one step of the horizontal slide: s(t) = s(t-1) + byte(30 + t) - byte(t), bytes numbered through d[0..11]
+template <int T>
+__device__ __forceinline__ int hslide(int s, const uint32_t (&d)[12])
+{
+    return sub_byte<T & 3>(add_byte<(30 + T) & 3>(s, d[(30 + T) >> 2]), d[T >> 2]);
+}
+
+// number of the four bytes of x that are > T, for a constant T prepared by swar_gt_prepare
+struct SwarGt { uint32_t add; int mode; };     // mode 0: none, 1: all, 2: T < 128, 3: T >= 128
+__device__ __forceinline__ SwarGt swar_gt_prepare(int T)
+{
+    SwarGt g;
+    g.mode = T >= 255 ? 0 : (T < 0 ? 1 : (T < 128 ? 2 : 3));
+    g.add = (uint32_t)(0x7f - (T & 0x7f)) * 0x01010101u;
+    return g;
+}
+__device__ __forceinline__ unsigned swar_count_gt(uint32_t x, const SwarGt &g)
+{
+    if (g.mode == 0) return 0;
+    if (g.mode == 1) return 4;
+    const uint32_t low = (x & 0x7f7f7f7fu) + g.add;         // bit 7 of a byte: (x & 127) > (T & 127); no carry between bytes
+    const uint32_t m = (g.mode == 2 ? (low | x) : (low & x)) & 0x80808080u;
+    return __builtin_popcount(m);
+}
+
 template <int MAXN, bool FULL>
-__device__ __forceinline__ float background_px(const uint32_t (&v)[MAXN], int j, const BgConst &bc, double coeff,
-                                               const double *rcp, const float *rcpf)
+__device__ __forceinline__ BgSums background_sums(const uint32_t (&v)[MAXN], int j, const BgConst &bc)
 {
     const int n = FULL ? MAXN : bc.n;
     int b[MAXN];
@@ -143,32 +207,41 @@ __device__ __forceinline__ float background_px(const uint32_t (&v)[MAXN], int j,
     for (int k = 0; k < MAXN; ++k) {
         b[k] = (int)__builtin_amdgcn_ubfe(v[k], 8 * j, 8);     // slots k >= n hold 0
         S += b[k];
-        Q = __umul24(b[k], b[k]) + Q;
+        Q = k == 0 ? (int)__umul24(b[k], b[k]) : (int)mad_u24(b[k], b[k], Q);
     }
-    const int D1 = __mul24(n, Q) - __mul24(S, S) + 1;     // D + 1
-    int Si = 0, c = 0;
-    unsigned z = ~0u;                                            // becomes 0 when some kept neighbour ties (u^2 == D)
-    bool hard = false;
+    const int negS = -S;
+    const int negD1 = mad_i24(S, S, mad_i24(Q, -n, -1));        // -(D + 1), D = n Q - S^2
+    BgSums r;
+    r.Si = 0; r.c = 0; r.hard = false;
+    unsigned z = 0;                                              // all ones when some kept neighbour ties (u^2 == D)
 #pragma unroll
     for (int k = 0; k < MAXN; ++k) {
         if (FULL || k < n) {                                    // workgroup-uniform
-            const int t = __mul24(n, b[k]) - S;
+            const int t = mad_i24(b[k], n, negS);
             const int u = max(t, 0);
-            const int w = __mul24(u, u) - D1;  // w < 0  <=>  u^2 <= D
+            const int w = mad_i24(u, u, negD1);                 // w < 0  <=>  u^2 <= D;  w == -1  <=>  u^2 == D
             const unsigned m = (unsigned)w >> 31;
-            Si = __umul24(b[k], m) + Si;
-            c += m;
-            z = min(z, ~(unsigned)w);
-            if (MAXN > 6) hard |= t > 0 && (unsigned)(w + 3) <= 4u && w != -1;   // 0 < |u^2 - D| < 3
+            r.Si = mad_u24(b[k], m, r.Si);
+            r.c += m;
+            z = max(z, (unsigned)w);
+            if (MAXN > 6) r.hard |= t > 0 && (unsigned)(w + 3) <= 4u && w != -1;   // 0 < |u^2 - D| < 3
         }
     }
-    if (z == 0) {                                                // a tie: exact only when S / n is dyadic
-        const int q = (int)(((unsigned)S * bc.magic) >> 16);
-        hard |= S - q * bc.nodd != 0;
-    }
-    hard |= !bc.unit_coeff;
-    if (__builtin_expect(hard, 0)) return background_px_chain<MAXN>(b, n, coeff, rcp);
-    return div_small((float)Si, (float)c, rcpf[c]);             // c >= 1: the smallest neighbour has t <= 0
+    // a tie is exact only when S / n is dyadic (branch-free: the test is three instructions)
+    const int q = (int)(((unsigned)S * bc.magic) >> 16);
+    r.hard |= z == ~0u && S - q * bc.nodd != 0;
+    return r;
+}
+
+// the reference's float chain for pixel j of the four in v (the pixels background_sums could not decide)
+template <int MAXN> struct NeighbourRow { uint32_t v[MAXN]; };      // by value: travels in registers, not scratch
+template <int MAXN>
+__device__ __noinline__ float background_hard(NeighbourRow<MAXN> row, int j, int n, double coeff, const double *rcp)
+{
+    int b[MAXN];
+#pragma unroll
+    for (int k = 0; k < MAXN; ++k) b[k] = (int)((row.v[k] >> (8 * j)) & 0xff);
+    return background_px_chain<MAXN>(b, n, coeff, rcp);
 }
 
 // ip.py:638: 30 + (bg / 255) * 225, three separately rounded f32 operations, then maximum(30, .).  bg is a
@@ -200,6 +273,125 @@ __device__ __forceinline__ uint32_t nibbles4(uint32_t d)
 {
     d = (d | (d >> 4)) & 0x00ff00ffu;
     return (d | (d >> 8)) & 0xffffu;
+}
+
+// Phase C of detect_kernel for one thread (see there).  FULL: the frame has all MAXN temporal neighbours.
+// FAST: the neighbour rows are read as aligned dwords at a 32-bit offset from a per-frame base that is uniform
+// over the workgroup (scalar registers), one add per row; no per-pixel bounds tests.
+template <int MAXN, bool FULL, bool FAST>
+__device__ __forceinline__ void pixel_rows(const DetectArgs &a, const uint8_t *s_win, const uint16_t *s_hs,
+                                           uint8_t (*s_nib)[TH][TW / 4], const double *s_rcp, const float *s_rcpf,
+                                           int x0, int y0, int fi, int lo, int nn, int cpos,
+                                           unsigned int &c_lt, unsigned int &c_gt)
+{
+    const int tid = threadIdx.x;
+    const int H = a.H, W = a.W;
+    const bool aligned = (W & 3) == 0;
+    BgConst bc;
+    bc.n = nn;
+    bc.nodd = nn > 0 ? nn >> __builtin_ctz(nn) : 1;
+    bc.magic = (65536u + bc.nodd - 1) / bc.nodd;
+    bc.unit_coeff = a.coeff == 1.0;
+    const int cg = tid & 31, rg = tid >> 5;
+    const int gx = x0 + 4 * cg;
+    const bool col_live = gx < W;
+    int vs[4] = {0, 0, 0, 0};
+    {
+        // 30 rows of packed u16 pairs: up to 8 rows (8 * 30 * 255 < 2^16) are added as whole dwords before widening
+        const uint16_t *hp = s_hs + (RG * rg) * HS_STRIDE + 4 * cg;
+#pragma unroll
+        for (int g = 0; g < KS; g += 8) {
+            uint32_t px = 0, py = 0;
+#pragma unroll
+            for (int i = g; i < (g + 8 < KS ? g + 8 : KS); ++i) {
+                const uint2 h = *reinterpret_cast<const uint2 *>(hp + i * HS_STRIDE);
+                px += h.x; py += h.y;
+            }
+            vs[0] += px & 0xffff; vs[1] += px >> 16; vs[2] += py & 0xffff; vs[3] += py >> 16;
+        }
+    }
+    const SwarGt sw_gt = swar_gt_prepare(a.frame_gt), sw_ge = swar_gt_prepare(a.est_lt - 1);
+    const size_t P = (size_t)H * W;
+    // neighbour frames of one row: slot s holds frame lo + s (+1 from the centre on)
+    auto load_row = [&](int gy, uint32_t (&v)[MAXN]) {
+        if (FAST) {
+            const unsigned off = (unsigned)(min(gy, H - 1) * W + gx);
+#pragma unroll
+            for (int s = 0; s < MAXN; ++s) {
+                const uint8_t *fb = a.frames + (size_t)(lo + s + (s >= cpos ? 1 : 0)) * P;    // uniform
+                v[s] = (FULL || s < nn) ? *reinterpret_cast<const uint32_t *>(fb + off) : 0u;
+            }
+        } else {
+#pragma unroll
+            for (int s = 0; s < MAXN; ++s) {
+                const int f = lo + s + (s >= cpos ? 1 : 0);
+                v[s] = (s < nn && col_live && gy < H) ? load4(a.frames + ((size_t)f * H + gy) * W, gx, W, aligned) : 0u;
+            }
+        }
+    };
+    uint32_t vnext[MAXN];
+    load_row(y0 + RG * rg, vnext);
+#pragma unroll 1
+    for (int r = 0; r < RG; ++r) {
+        const int ty = RG * rg + r;
+        const int gy = y0 + ty;
+        uint32_t v[MAXN];
+#pragma unroll
+        for (int s = 0; s < MAXN; ++s) v[s] = vnext[s];
+        if (r + 1 < RG) load_row(gy + 1, vnext);             // in flight under this row's arithmetic
+        uint32_t dm = 0, bm = 0;
+        if (FAST || (gy < H && col_live)) {
+            const uint32_t cen = *reinterpret_cast<const uint32_t *>(s_win + (ty + AX) * WIN_STRIDE + 16 + 4 * cg);
+            unsigned lt = 0, gt = 0;
+            BgSums sm[4];
+            bool any_hard = !bc.unit_coeff;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                sm[j] = background_sums<MAXN, FULL>(v, j, bc);
+                any_hard |= sm[j].hard;
+            }
+            float bgv[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bgv[j] = div_small((float)sm[j].Si, (float)sm[j].c, s_rcpf[sm[j].c]);   // c >= 1
+            if (__builtin_expect(any_hard, 0)) {
+                NeighbourRow<MAXN> row;
+#pragma unroll
+                for (int s = 0; s < MAXN; ++s) row.v[s] = v[s];
+                for (int j = 0; j < 4; ++j)
+                    if (sm[j].hard || !bc.unit_coeff) {
+                        const float h = background_hard<MAXN>(row, j, FULL ? MAXN : nn, a.coeff, s_rcp);
+                        bgv[0] = j == 0 ? h : bgv[0]; bgv[1] = j == 1 ? h : bgv[1];
+                        bgv[2] = j == 2 ? h : bgv[2]; bgv[3] = j == 3 ? h : bgv[3];
+                    }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (FAST || gx + j < W) {
+                    const int pix = (int)__builtin_amdgcn_ubfe(cen, 8 * j, 8);
+                    const float bg = bgv[j];
+                    if (!FAST && a.bg_out) a.bg_out[(size_t)gy * W + gx + j] = bg;
+                    const float thr = damage_threshold_f32(bg);
+                    const bool dmg = ((float)pix > thr) && (900 * pix > vs[j]);
+                    dm |= (uint32_t)dmg << j;
+                    bm |= (uint32_t)(bg > a.bg_gt) << j;
+                    if (!FAST) { lt += pix < a.est_lt; gt += pix > a.frame_gt; }
+                }
+            }
+            if (FAST) { gt = swar_count_gt(cen, sw_gt); lt = 4 - swar_count_gt(cen, sw_ge); }
+            if (!FAST || gy < H) { c_lt += lt; c_gt += gt; }
+        }
+        s_nib[0][ty][cg] = (uint8_t)dm;
+        s_nib[1][ty][cg] = (uint8_t)bm;
+        if (r + 1 < RG) {                                    // slide the window one row down
+            const uint2 hin = *reinterpret_cast<const uint2 *>(s_hs + (ty + KS) * HS_STRIDE + 4 * cg);
+            const uint2 hout = *reinterpret_cast<const uint2 *>(s_hs + ty * HS_STRIDE + 4 * cg);
+            typedef unsigned short ipx_u16x2 __attribute__((ext_vector_type(2)));
+            const ipx_u16x2 dx = __builtin_bit_cast(ipx_u16x2, hin.x) - __builtin_bit_cast(ipx_u16x2, hout.x);   // per lane, mod 2^16
+            const ipx_u16x2 dy = __builtin_bit_cast(ipx_u16x2, hin.y) - __builtin_bit_cast(ipx_u16x2, hout.y);
+            vs[0] += (int)(short)dx.x; vs[1] += (int)(short)dx.y;
+            vs[2] += (int)(short)dy.x; vs[3] += (int)(short)dy.y;
+        }
+    }
 }
 
 template <int MAXN>
@@ -279,18 +471,20 @@ __global__ __launch_bounds__(256) void detect_kernel(DetectArgs a)
         uint32_t d[12];
 #pragma unroll
         for (int j = 0; j < 12; ++j) d[j] = rp[j];
-        auto byte_at = [&](int q) -> int { return (d[q >> 2] >> (8 * (q & 3))) & 0xff; };
-        int s = 0;
+        // bytes 1..30: three of d[0], all of d[1..6], three of d[7] (sums of four bytes in one instruction each)
+        int s0 = (int)__builtin_amdgcn_sad_u8(d[0] & 0xffffff00u, 0u, 0u);
 #pragma unroll
-        for (int i = 1; i <= 30; ++i) s += byte_at(i);
+        for (int j = 1; j <= 6; ++j) s0 = (int)__builtin_amdgcn_sad_u8(d[j], 0u, (unsigned)s0);
+        s0 = (int)__builtin_amdgcn_sad_u8(d[7] & 0x00ffffffu, 0u, (unsigned)s0);
+        int sv[16];
+        sv[0] = s0;
+        sv[1] = hslide<1>(sv[0], d);   sv[2] = hslide<2>(sv[1], d);   sv[3] = hslide<3>(sv[2], d);   sv[4] = hslide<4>(sv[3], d);
+        sv[5] = hslide<5>(sv[4], d);   sv[6] = hslide<6>(sv[5], d);   sv[7] = hslide<7>(sv[6], d);   sv[8] = hslide<8>(sv[7], d);
+        sv[9] = hslide<9>(sv[8], d);   sv[10] = hslide<10>(sv[9], d); sv[11] = hslide<11>(sv[10], d); sv[12] = hslide<12>(sv[11], d);
+        sv[13] = hslide<13>(sv[12], d); sv[14] = hslide<14>(sv[13], d); sv[15] = hslide<15>(sv[14], d);
         uint32_t out[8];
-        int prev = s;
 #pragma unroll
-        for (int t = 1; t < 16; ++t) {
-            s += byte_at(30 + t) - byte_at(t);
-            if (t & 1) out[t >> 1] = (uint32_t)prev | ((uint32_t)s << 16);
-            else prev = s;
-        }
+        for (int t = 0; t < 8; ++t) out[t] = (uint32_t)sv[2 * t] | ((uint32_t)sv[2 * t + 1] << 16);
         uint32_t *hp = reinterpret_cast<uint32_t *>(s_hs + r * HS_STRIDE + seg * 16);
 #pragma unroll
         for (int j = 0; j < 8; ++j) hp[j] = out[j];
@@ -303,72 +497,14 @@ __global__ __launch_bounds__(256) void detect_kernel(DetectArgs a)
     const int nn = hi - lo - 1;                              // neighbours (centre excluded)
     const int cpos = fi - lo;                                // centre's slot in the window
     const bool full = nn == MAXN;                            // workgroup-uniform
-    BgConst bc;
-    bc.n = nn;
-    bc.nodd = nn > 0 ? nn >> __builtin_ctz(nn) : 1;
-    bc.magic = (65536u + bc.nodd - 1) / bc.nodd;
-    bc.unit_coeff = a.coeff == 1.0;
-    const int cg = tid & 31, rg = tid >> 5;
-    const int gx = x0 + 4 * cg;
+    // FAST: every 4-pixel group of the tile lies inside the image and is dword-aligned (rows below the image are
+    // computed from the last row and dropped), nothing but the two planes leaves the kernel
+    const bool fast = aligned && x0 + TW <= W && a.bg_out == nullptr;
     unsigned int c_lt = 0, c_gt = 0;
-    const bool col_live = gx < W;
-    int vs[4] = {0, 0, 0, 0};
-    {
-        const uint16_t *hp = s_hs + (RG * rg) * HS_STRIDE + 4 * cg;
-#pragma unroll 6
-        for (int i = 0; i < KS; ++i) {
-            const uint2 h = *reinterpret_cast<const uint2 *>(hp + i * HS_STRIDE);
-            vs[0] += h.x & 0xffff; vs[1] += h.x >> 16; vs[2] += h.y & 0xffff; vs[3] += h.y >> 16;
-        }
-    }
-    // neighbour frames of one row: slot s holds frame lo + s (+1 from the centre on)
-    auto load_row = [&](int gy, uint32_t (&v)[MAXN]) {
-#pragma unroll
-        for (int s = 0; s < MAXN; ++s) {
-            const int f = lo + s + (s >= cpos ? 1 : 0);
-            v[s] = (s < nn && col_live && gy < H) ? load4(a.frames + ((size_t)f * H + gy) * W, gx, W, aligned) : 0u;
-        }
-    };
-    uint32_t vnext[MAXN];
-    load_row(y0 + RG * rg, vnext);
-#pragma unroll 1
-    for (int r = 0; r < RG; ++r) {
-        const int ty = RG * rg + r;
-        const int gy = y0 + ty;
-        uint32_t v[MAXN];
-#pragma unroll
-        for (int s = 0; s < MAXN; ++s) v[s] = vnext[s];
-        if (r + 1 < RG) load_row(gy + 1, vnext);             // in flight under this row's arithmetic
-        uint32_t dm = 0, bm = 0;
-        if (gy < H && col_live) {
-            const uint32_t cen = *reinterpret_cast<const uint32_t *>(s_win + (ty + AX) * WIN_STRIDE + 16 + 4 * cg);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                if (gx + j < W) {
-                    const int pix = (cen >> (8 * j)) & 0xff;
-                    const float bg = full ? background_px<MAXN, true>(v, j, bc, a.coeff, s_rcp, s_rcpf)
-                                          : background_px<MAXN, false>(v, j, bc, a.coeff, s_rcp, s_rcpf);
-                    if (a.bg_out) a.bg_out[(size_t)gy * W + gx + j] = bg;
-                    const float thr = damage_threshold_f32(bg);
-                    const bool dmg = ((float)pix > thr) && (900 * pix > vs[j]);
-                    dm |= (uint32_t)dmg << j;
-                    bm |= (uint32_t)(bg > a.bg_gt) << j;
-                    c_lt += pix < a.est_lt;
-                    c_gt += pix > a.frame_gt;
-                }
-            }
-        }
-        s_nib[0][ty][cg] = (uint8_t)dm;
-        s_nib[1][ty][cg] = (uint8_t)bm;
-        if (r + 1 < RG) {                                    // slide the window one row down
-            const uint2 hin = *reinterpret_cast<const uint2 *>(s_hs + (ty + KS) * HS_STRIDE + 4 * cg);
-            const uint2 hout = *reinterpret_cast<const uint2 *>(s_hs + ty * HS_STRIDE + 4 * cg);
-            vs[0] += (int)(hin.x & 0xffff) - (int)(hout.x & 0xffff);
-            vs[1] += (int)(hin.x >> 16) - (int)(hout.x >> 16);
-            vs[2] += (int)(hin.y & 0xffff) - (int)(hout.y & 0xffff);
-            vs[3] += (int)(hin.y >> 16) - (int)(hout.y >> 16);
-        }
-    }
+    if (full && fast) pixel_rows<MAXN, true, true>(a, s_win, s_hs, s_nib, s_rcp, s_rcpf, x0, y0, fi, lo, nn, cpos, c_lt, c_gt);
+    else if (full) pixel_rows<MAXN, true, false>(a, s_win, s_hs, s_nib, s_rcp, s_rcpf, x0, y0, fi, lo, nn, cpos, c_lt, c_gt);
+    else if (fast) pixel_rows<MAXN, false, true>(a, s_win, s_hs, s_nib, s_rcp, s_rcpf, x0, y0, fi, lo, nn, cpos, c_lt, c_gt);
+    else pixel_rows<MAXN, false, false>(a, s_win, s_hs, s_nib, s_rcp, s_rcpf, x0, y0, fi, lo, nn, cpos, c_lt, c_gt);
     if (a.dense) {
         // wave-level reduce, then one LDS atomic per wave
         for (int off = 32; off > 0; off >>= 1) {
