@@ -12,39 +12,60 @@
 
 namespace {
 
-// Bit-sliced saturating run-length counters: K planes of 64 lanes each.
-template <int K>
-__global__ void persistent_kernel(const uint64_t *raw, const uint8_t *keep, int n, size_t words, int T,
-                                  uint64_t valid_unused, uint64_t *out)
+// Bit-sliced saturating run-length counters: K planes of 64 lanes each.  The n planes are cut into groups of
+// `group` planes (blockIdx.y); a group also walks the T-1 planes before its own, so every run of >= T planes is
+// seen whole by the group its T-th plane falls into (the same argument as for frame-range shards, include/ipx.h),
+// and the groups' results are OR-ed into `out` (zeroed by the caller).  A lane that walked all n planes alone
+// was one chain of n dependent-issue loads on half the CUs.
+template <int K, bool HAS_KEEP>
+__global__ void persistent_kernel(const uint64_t *raw, const uint8_t *keep, int n, size_t words, int T, int group,
+                                  uint64_t *out)
 {
     const size_t w = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (w >= words) return;
-    uint64_t c[K];
+    const int i1 = min(n, ((int)blockIdx.y + 1) * group);
+    const int i0 = max(0, (int)blockIdx.y * group - (T - 1));
+    uint64_t c[K], tb[K];
 #pragma unroll
-    for (int k = 0; k < K; ++k) c[k] = 0;
+    for (int k = 0; k < K; ++k) { c[k] = 0; tb[k] = ((T >> k) & 1) ? ~0ull : 0ull; }
     uint64_t pers = 0;
-    for (int i = 0; i < n; ++i) {
-        const uint64_t m = (keep == nullptr || keep[i]) ? raw[(size_t)i * words + w] : 0ull;   // None resets runs
-        // cnt = m ? min(cnt + 1, 2^K - 1) : 0
-        uint64_t carry = m;
+    constexpr int B = 8;                                  // planes loaded together: B independent loads in flight
+#pragma unroll 1
+    for (int i = i0; i < i1; i += B) {
+        uint64_t mm[B];
 #pragma unroll
-        for (int k = 0; k < K; ++k) {
-            const uint64_t t = c[k] & carry;
-            c[k] ^= carry;
-            carry = t;
+        for (int u = 0; u < B; ++u) {
+            // planes past the end are read as the last plane and zeroed (no branch between the loads); a zero plane
+            // after the last one only resets counters that are not looked at again
+            const int iu = min(i + u, i1 - 1);
+            uint64_t m = raw[(size_t)iu * words + w];
+            if (HAS_KEEP) m &= keep[iu] ? ~0ull : 0ull;   // None resets runs
+            mm[u] = i + u < i1 ? m : 0ull;
         }
 #pragma unroll
-        for (int k = 0; k < K; ++k) c[k] = (c[k] | carry) & m;     // saturate on overflow, reset where m = 0
-        // ge = cnt >= T, MSB-first comparison against the constant T
-        uint64_t gt = 0, eq = ~0ull;
+        for (int u = 0; u < B; ++u) {
+            const uint64_t m = mm[u];
+            // cnt = m ? min(cnt + 1, 2^K - 1) : 0
+            uint64_t carry = m;
 #pragma unroll
-        for (int k = K - 1; k >= 0; --k) {
-            if ((T >> k) & 1) eq &= c[k];
-            else { gt |= eq & c[k]; eq &= ~c[k]; }
+            for (int k = 0; k < K; ++k) {
+                const uint64_t t = c[k] & carry;
+                c[k] ^= carry;
+                carry = t;
+            }
+#pragma unroll
+            for (int k = 0; k < K; ++k) c[k] = (c[k] | carry) & m;     // saturate on overflow, reset where m = 0
+            // ge = cnt >= T, MSB-first comparison against T (tb[k] = all ones where bit k of T is set; branch-free)
+            uint64_t gt = 0, eq = ~0ull;
+#pragma unroll
+            for (int k = K - 1; k >= 0; --k) {
+                gt |= eq & c[k] & ~tb[k];
+                eq &= ~(c[k] ^ tb[k]);
+            }
+            pers |= gt | eq;
         }
-        pers |= gt | eq;
     }
-    out[w] = pers;
+    if (pers) atomicOr(reinterpret_cast<unsigned long long *>(out + w), (unsigned long long)pers);
 }
 
 __global__ void fill_plane_kernel(uint64_t *out, int H, int W, int wpr)
@@ -133,21 +154,37 @@ __global__ void static_from_maps_kernel(const int32_t *heat, const int32_t *vali
     if (lane == 0) out[word] = b;
 }
 
-// final planes + per-frame counters {sum(final), #(final & f < est_lt), #(final & f > frame_gt)}
-__global__ void finalize_kernel(const uint8_t *frames, const uint64_t *raw, const uint64_t *pers,
-                                const uint64_t *stat, const uint8_t *keep, int H, int W, int wpr,
-                                int est_lt, int frame_gt, uint64_t *fin, unsigned long long *counts)
+// final planes + per-frame counters {sum(final), #(final & f < est_lt), #(final & f > frame_gt)}.
+// A thread owns two adjacent words of one frame; the counters are reduced per wave, then per workgroup in LDS,
+// and leave as at most three atomics per workgroup (one per wave and counter saturated the atomic unit: the
+// planes are sparse, but nearly every wave holds a few set bits).
+constexpr int FIN_WPT = 2;
+__global__ __launch_bounds__(256) void finalize_kernel(const uint8_t *frames, const uint64_t *raw, const uint64_t *pers,
+                                                       const uint64_t *stat, const uint8_t *keep, int H, int W, int wpr,
+                                                       int est_lt, int frame_gt, uint64_t *fin, unsigned long long *counts)
 {
+    __shared__ unsigned s_c[3];
     const size_t words = (size_t)H * wpr;
     const int i = blockIdx.y;
-    const size_t w = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t w0 = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * FIN_WPT;
+    if (threadIdx.x < 3) s_c[threadIdx.x] = 0;
+    __syncthreads();
+    const bool kept = keep == nullptr || keep[i];
     unsigned c0 = 0, c1 = 0, c2 = 0;
-    if (w < words) {
-        uint64_t m = 0;
-        if (keep == nullptr || keep[i]) m = raw[(size_t)i * words + w] & ~(pers[w] | (stat ? stat[w] : 0ull));
-        if (fin) fin[(size_t)i * words + w] = m;
+    uint64_t r[FIN_WPT], bad[FIN_WPT];
+#pragma unroll
+    for (int k = 0; k < FIN_WPT; ++k) {
+        const size_t w = w0 + k;
+        r[k] = (kept && w < words) ? raw[(size_t)i * words + w] : 0ull;
+        bad[k] = w < words ? (pers[w] | (stat ? stat[w] : 0ull)) : 0ull;
+    }
+#pragma unroll
+    for (int k = 0; k < FIN_WPT; ++k) {
+        const size_t w = w0 + k;
+        const uint64_t m = r[k] & ~bad[k];
+        if (fin && w < words) fin[(size_t)i * words + w] = m;
         if (m) {
-            c0 = __builtin_popcountll(m);
+            c0 += __builtin_popcountll(m);
             const size_t y = w / wpr;
             const uint8_t *row = frames + ((size_t)i * H + y) * W + (w - y * wpr) * 64;
             uint64_t rem = m;
@@ -166,10 +203,10 @@ __global__ void finalize_kernel(const uint8_t *frames, const uint64_t *raw, cons
         c2 += __shfl_down(c2, off);
     }
     if ((threadIdx.x & 63) == 0 && (c0 | c1 | c2)) {
-        atomicAdd(counts + (size_t)i * 3 + 0, (unsigned long long)c0);
-        atomicAdd(counts + (size_t)i * 3 + 1, (unsigned long long)c1);
-        atomicAdd(counts + (size_t)i * 3 + 2, (unsigned long long)c2);
+        atomicAdd(&s_c[0], c0); atomicAdd(&s_c[1], c1); atomicAdd(&s_c[2], c2);
     }
+    __syncthreads();
+    if (threadIdx.x < 3 && s_c[threadIdx.x]) atomicAdd(counts + (size_t)i * 3 + threadIdx.x, (unsigned long long)s_c[threadIdx.x]);
 }
 
 // per-frame {#(frame < est_lt), #(frame > frame_gt)}: the mask-independent inputs of ip.py:800-805, :840
@@ -224,12 +261,24 @@ extern "C" int ipx_persistent_mask(ipx_ctx *ctx, const uint64_t *raw_bits, const
         IPX_LAUNCH(ctx, KID_PERSISTENT, words * 8, fill_plane_kernel, grid, block, persistent_bits, H, W, wpr);
     } else if (T > n) {               // no run can be that long
         IPX_CHECK_HIP(hipMemsetAsync(persistent_bits, 0, words * 8, ctx->stream));
-    } else if (T < 4) {
-        IPX_LAUNCH(ctx, KID_PERSISTENT, (n + 1.0) * words * 8, persistent_kernel<2>, grid, block, raw_bits, keep, n, words, T, 0ull, persistent_bits);
-    } else if (T < 256) {
-        IPX_LAUNCH(ctx, KID_PERSISTENT, (n + 1.0) * words * 8, persistent_kernel<8>, grid, block, raw_bits, keep, n, words, T, 0ull, persistent_bits);
     } else {
-        IPX_LAUNCH(ctx, KID_PERSISTENT, (n + 1.0) * words * 8, persistent_kernel<24>, grid, block, raw_bits, keep, n, words, T, 0ull, persistent_bits);
+        // groups of >= 32 planes, and at least 4 (T-1) so that the overlap stays below a quarter of the reads
+        long long group = 32;
+        if (group < 4LL * (T - 1)) group = 4LL * (T - 1);
+        if (group > n) group = n;
+        const unsigned ng = (unsigned)((n + group - 1) / group);
+        const dim3 g2(grid.x, ng);
+        IPX_CHECK_HIP(hipMemsetAsync(persistent_bits, 0, words * 8, ctx->stream));
+        const double ab = (n + 1.0) * words * 8;
+#define IPX_PERS(K)                                                                                                        \
+        do {                                                                                                               \
+            if (keep) IPX_LAUNCH(ctx, KID_PERSISTENT, ab, (persistent_kernel<K, true>), g2, block, raw_bits, keep, n, words, T, (int)group, persistent_bits); \
+            else IPX_LAUNCH(ctx, KID_PERSISTENT, ab, (persistent_kernel<K, false>), g2, block, raw_bits, keep, n, words, T, (int)group, persistent_bits);     \
+        } while (0)
+        if (T < 4) IPX_PERS(2);
+        else if (T < 256) IPX_PERS(8);
+        else IPX_PERS(24);
+#undef IPX_PERS
     }
     IPX_LAUNCH_CHECK();
     return IPX_OK;
@@ -277,7 +326,7 @@ extern "C" int ipx_finalize(ipx_ctx *ctx, const uint8_t *frames, const uint64_t 
     const int wpr = ipx_wpr(W);
     const size_t words = (size_t)H * wpr;
     IPX_CHECK_HIP(hipMemsetAsync(counts, 0, sizeof(int64_t) * 3 * (size_t)n, ctx->stream));
-    const dim3 grid((unsigned)((words + 255) / 256), n), block(256);
+    const dim3 grid((unsigned)((words + 256 * FIN_WPT - 1) / (256 * FIN_WPT)), n), block(256);
     IPX_LAUNCH(ctx, KID_FINALIZE, (2.0 * n + 2.0) * words * 8, finalize_kernel, grid, block, frames, raw_bits, persistent_bits, static_bits,
                        keep, H, W, wpr, d.est_lt, d.frame_gt, final_bits, (unsigned long long *)counts);
     IPX_LAUNCH_CHECK();

@@ -30,7 +30,7 @@ def main():
         if stage == "detect":
             eng.detect_raw(fr, keep)
         else:
-            pers = eng.persistent_mask(raw, keep, H, W)
+            pers = eng.persistent_mask(raw, None, H, W)
             maps = eng.static_maps(fr, raw, pers, keep)
             stat = eng.static_from_maps(maps)
             eng.finalize(fr, raw, pers, stat, keep, want_bits=True)
