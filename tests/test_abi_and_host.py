@@ -143,3 +143,46 @@ def test_f32_quotients_via_f64_reciprocal_are_exact():
     bg = np.concatenate(quot + [rng.uniform(0, 256, 2_000_000).astype(np.float32),
                                 np.ldexp(rng.integers(1, 1 << 24, 500_000).astype(np.float32), -16)])
     assert np.array_equal(bg / np.float32(255.0), (bg.astype(np.float64) * (1.0 / 255.0)).astype(np.float32))
+
+
+def test_f32_quotients_by_residual_correction_are_exact():
+    """csrc/detect.hip (div_small) forms Si/c and bg/255 in f32 as q = RN(a*y), q + RN(a - b*q)*y with
+    y = RN32(1/b) and the residual from an fma.  Walked through exactly (rationals) for every Si/c a window of
+    up to 16 neighbours can produce and for every such quotient divided by 255: the result is the IEEE f32 quotient."""
+    from fractions import Fraction as F
+    import math
+
+    def rn32(fr):
+        if fr == 0:
+            return F(0)
+        sgn = 1 if fr > 0 else -1
+        a = abs(fr)
+        e = math.floor(math.log2(float(a)))
+        while F(2) ** e > a:
+            e -= 1
+        while F(2) ** (e + 1) <= a:
+            e += 1
+        q = F(2) ** (e - 23)
+        k = a / q
+        fl = k.numerator // k.denominator
+        rem = k - fl
+        if rem > F(1, 2) or (rem == F(1, 2) and fl % 2 == 1):
+            fl += 1
+        return sgn * fl * q
+
+    def div_small(a, b, y):
+        q = rn32(a * y)
+        r = rn32(a - b * q)                              # fma: one rounding of the exact residual
+        return rn32(q + r * y)
+
+    bgs = set()
+    for c in range(1, 17):
+        y = rn32(F(1, c))
+        assert y == F(float(np.float32(1.0) / np.float32(c)))
+        for si in range(0, 255 * c + 1):
+            exact = rn32(F(si, c))
+            assert div_small(F(si), F(c), y) == exact, (si, c)
+            bgs.add(exact)
+    y = rn32(F(1, 255))
+    for bg in bgs:
+        assert div_small(bg, F(255), y) == rn32(bg / 255), float(bg)

@@ -75,6 +75,34 @@ def test_background_and_raw_planes(eng, S, shape, radius):
     eng.set_params(None)
 
 
+@pytest.mark.parametrize("radius", [1, 2, 3, 4, 6, 8])
+def test_background_integer_decision_on_ties_and_extremes(eng, S, radius):
+    """detect.hip decides _find_background's outlier cut in integers wherever that is provably the reference's
+    decision and runs the float chain elsewhere.  Frames drawn from a few grey levels make exact ties
+    (t^2 == D, dyadic and non-dyadic means), near-ties and zero variance common; 0 / 255 mixtures reach the
+    largest D; chunk edges give every neighbour count from radius to 2 radius.  The f32 background must equal the
+    oracle's float chain bit for bit, also for a coefficient other than 1 (which always takes the chain)."""
+    rng = np.random.default_rng(100 + radius)
+    h, w, n = 40, 136, 2 * radius + 4
+    for levels in ([0, 255], [7, 8], [10, 11, 13], [0, 1, 2, 3], [100, 101, 102, 103, 104, 105, 250], list(range(256))):
+        frames = rng.choice(np.array(levels, np.uint8), size=(n, h, w))
+        frames[:, :4, :8] = levels[0]                                    # a flat patch: D = 0
+        for coeff in (1.0, 0.5, 1.75):
+            eng.set_params(dict(sliding_window_radius=radius, pixel_std_coeff=coeff))
+            fd = eng.to_device(frames)
+            for i in (0, 1, radius, n // 2, n - 2, n - 1):
+                exp = S.compute_background(frames, i, radius, coeff)
+                got = eng.background(fd, i).cpu().numpy()
+                assert np.array_equal(got, exp), (levels[:4], coeff, i, int((got != exp).sum()))
+            if coeff == 1.0:                                             # the planes of the fused kernel as well
+                raw, bright, _ = eng.detect_raw(fd)
+                raw = _bits_to_bool(eng, raw, h, w)
+                for i in (0, n // 2, n - 1):
+                    bg = S.compute_background(frames, i, radius)
+                    assert np.array_equal(raw[i], S.raw_damaged_mask(frames[i], bg))
+    eng.set_params(None)
+
+
 def test_raw_planes_discarded_frames_are_zero(eng, S):
     import torch
     frames = _chunk(3, 8, 48, 80, hot=10.0)
