@@ -765,7 +765,7 @@ def _load_chunk_gray_avi(video_filename, start, end):
     except (OSError, ValueError):
         return None
     try:
-        if reader.bpp != 8:
+        if not reader.grey_palette:                     # colour, or indices that are not grey levels: the general path
             return None
         start, end = int(start or 0), min(int(end), reader.frame_count) if end else reader.frame_count
         n = end - start

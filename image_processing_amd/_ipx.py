@@ -65,6 +65,9 @@ PROTOTYPES = {
     "ipx_profile_kernel_classes": (_i, []),
     "ipx_profile_read": (_i, [_ctx, _i, C.POINTER(C.c_char_p), C.POINTER(C.c_uint64), C.POINTER(C.c_double),
                               C.POINTER(C.c_double)]),
+    "ipx_host_register": (_i, [_p, C.c_size_t]),
+    "ipx_host_unregister": (_i, [_p]),
+    "ipx_upload_frames": (_i, [_ctx, _p, C.c_size_t, _p]),
     "ipx_bgr2gray": (_i, [_ctx, _p, C.c_size_t, _p]),
     "ipx_flow_metric": (_i, [_ctx, _p, _i, _i, _i, _p, _p, _p]),
     "ipx_flow_status": (_i, [_ctx, C.POINTER(_i), _i]),

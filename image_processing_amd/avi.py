@@ -76,21 +76,27 @@ class AviReader:
 
     def __init__(self, filename):
         self.filename = filename
+        self._mm = None
         self._fh = open(filename, "rb")
-        size = os.fstat(self._fh.fileno()).st_size
-        if size < 12:
-            raise ValueError("%s: not an AVI file" % filename)
-        self._mm = mmap.mmap(self._fh.fileno(), 0, access=mmap.ACCESS_READ)
-        mm = self._mm
-        if mm[0:4] != b"RIFF" or mm[8:12] != b"AVI ":
-            raise ValueError("%s: not a RIFF AVI file" % filename)
-        self.fps = 0.0
-        self.width = self.height = self.bpp = 0
-        self._frames = []                                   # (offset, length)
-        self._walk(12, min(size, 8 + struct.unpack("<I", mm[4:8])[0]))
-        if not self.bpp:
-            raise ValueError("%s: no video stream format found" % filename)
-        self._stride = (self.width * self.bpp // 8 + 3) & ~3
+        try:
+            size = os.fstat(self._fh.fileno()).st_size
+            if size < 12:
+                raise ValueError("%s: not an AVI file" % filename)
+            self._mm = mmap.mmap(self._fh.fileno(), 0, access=mmap.ACCESS_READ)
+            mm = self._mm
+            if mm[0:4] != b"RIFF" or mm[8:12] != b"AVI ":
+                raise ValueError("%s: not a RIFF AVI file" % filename)
+            self.fps = 0.0
+            self.width = self.height = self.bpp = 0
+            self.palette = None                             # (256, 3) uint8 BGR for 8-bit streams
+            self._frames = []                               # (offset, length)
+            self._walk(12, min(size, 8 + struct.unpack("<I", mm[4:8])[0]))
+            if not self.bpp:
+                raise ValueError("%s: no video stream format found" % filename)
+            self._stride = (self.width * self.bpp // 8 + 3) & ~3
+        except Exception:                                   # nothing stays open behind a failed open
+            self.close()
+            raise
 
     def _walk(self, pos, end):
         mm = self._mm
@@ -116,6 +122,17 @@ class AviReader:
                                      "decode other streams with cv2" % (self.filename, mm[body + 16:body + 20], bpp))
                 self.width, self.height, self.bpp = w, abs(h), bpp
                 self._bottom_up = h > 0
+                if bpp == 8:                                # colour table: biClrUsed (0 = 256) entries of B, G, R, 0
+                    hdr = struct.unpack("<I", mm[body:body + 4])[0]
+                    used = struct.unpack("<I", mm[body + 32:body + 36])[0] if hdr >= 36 else 0
+                    count = min(used or 256, 256, max(0, (ln - hdr) // 4))
+                    pal = np.zeros((256, 3), np.uint8)
+                    if count:
+                        raw = np.frombuffer(mm, dtype=np.uint8, count=4 * count, offset=body + hdr).reshape(count, 4)
+                        pal[:count] = raw[:, :3]
+                    else:                                   # no table stored: grey ramp, as decoders assume
+                        pal[:] = np.arange(256, dtype=np.uint8)[:, None]
+                    self.palette = pal
             elif cc[2:4] in (b"db", b"dc") and cc[0:2].isdigit():
                 self._frames.append((body, ln))
             pos = body + ln + (ln & 1)
@@ -123,6 +140,13 @@ class AviReader:
     @property
     def frame_count(self):
         return len(self._frames)
+
+    @property
+    def grey_palette(self):
+        """True when an 8-bit stream's colour table is the identity grey ramp (entry i = (i, i, i)): only then are
+        the stored indices the grey levels a decoder + BGR2GRAY would return."""
+        return self.bpp == 8 and self.palette is not None and \
+            bool((self.palette == np.arange(256, dtype=np.uint8)[:, None]).all())
 
     def read(self, i):
         off, ln = self._frames[i]
@@ -155,7 +179,9 @@ class AviReader:
             except BufferError:
                 pass
             self._mm = None
+        if self._fh is not None:
             self._fh.close()
+            self._fh = None
 
 
 class VideoCapture:
@@ -196,13 +222,14 @@ class VideoCapture:
         f = self._r.read(self._pos)
         self._pos += 1
         if f.ndim == 2:
-            f = np.repeat(f[:, :, None], 3, axis=2)
+            f = self._r.palette[f]                          # indices through the colour table -> BGR, as cv2 does
         return True, f
 
     def is_gray(self):
-        """True for an 8-bit stream: read_gray() then returns the stored grey frames themselves (what
-        cvtColor(BGR2GRAY) gives back for the grey-coded BGR frames read() returns)."""
-        return self._r is not None and self._r.bpp == 8
+        """True for an 8-bit stream whose colour table is the grey ramp: read_gray() then returns the stored
+        frames themselves (what cvtColor(BGR2GRAY) gives back for the grey-coded BGR frames read() returns).
+        Any other table goes through read() and the luma conversion."""
+        return self._r is not None and self._r.grey_palette
 
     def read_gray(self):
         if self._r is None or self._pos >= self._r.frame_count:

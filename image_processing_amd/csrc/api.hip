@@ -71,6 +71,8 @@ extern "C" int ipx_ctx_create(int device, ipx_ctx **out)
     c->stream = nullptr;
     for (int i = 0; i < SLOT_COUNT; ++i) { c->slot[i] = nullptr; c->slot_bytes[i] = 0; }
     c->flow_plan = nullptr;
+    c->copy_stream = nullptr;
+    c->copy_done = nullptr;
     c->fi_spin_limit = 1u << 27;
     c->flow_ran = 0;
     memset(&c->prof, 0, sizeof(c->prof));
@@ -101,6 +103,11 @@ extern "C" int ipx_ctx_destroy(ipx_ctx *ctx)
     free(ctx->prof.recs);
     (void)hipEventDestroy(ctx->ev0);
     (void)hipEventDestroy(ctx->ev1);
+    if (ctx->copy_stream) {
+        (void)hipStreamSynchronize(ctx->copy_stream);
+        (void)hipStreamDestroy(ctx->copy_stream);
+        (void)hipEventDestroy(ctx->copy_done);
+    }
     delete ctx;
     return IPX_OK;
 }
@@ -158,6 +165,42 @@ extern "C" int ipx_synchronize(ipx_ctx *ctx)
                       "(frames discarded).  ipx_flow_status(ctx, &r, 1) clears the condition");
         return IPX_ERR_HIP;
     }
+    return IPX_OK;
+}
+
+// ---- input side: host frames -> HBM on a side stream ---------------------------------------------------------
+extern "C" int ipx_host_register(void *host, size_t bytes)
+{
+    IPX_REQUIRE(host && bytes > 0, "bad buffer");
+    const hipError_t e = hipHostRegister(host, bytes, hipHostRegisterDefault);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();                         // not sticky: the caller may go on with pageable memory
+        ipx_set_error("hipHostRegister of %zu bytes failed: %s (the copy still works from pageable memory)", bytes,
+                      hipGetErrorString(e));
+        return IPX_ERR_HIP;
+    }
+    return IPX_OK;
+}
+
+extern "C" int ipx_host_unregister(void *host)
+{
+    IPX_REQUIRE(host, "null pointer");
+    IPX_CHECK_HIP(hipHostUnregister(host));
+    return IPX_OK;
+}
+
+extern "C" int ipx_upload_frames(ipx_ctx *ctx, const uint8_t *host_frames, size_t bytes, uint8_t *dev_frames)
+{
+    IPX_REQUIRE(ctx && host_frames && dev_frames, "null pointer");
+    if (bytes == 0) return IPX_OK;
+    if (int e = ipx_ctx_enter(ctx)) return e;
+    if (!ctx->copy_stream) {
+        IPX_CHECK_HIP(hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+        IPX_CHECK_HIP(hipEventCreateWithFlags(&ctx->copy_done, hipEventDisableTiming));
+    }
+    IPX_CHECK_HIP(hipMemcpyAsync(dev_frames, host_frames, bytes, hipMemcpyHostToDevice, ctx->copy_stream));
+    IPX_CHECK_HIP(hipEventRecord(ctx->copy_done, ctx->copy_stream));
+    IPX_CHECK_HIP(hipStreamWaitEvent(ctx->stream, ctx->copy_done, 0));      // later work of the context sees the frames
     return IPX_OK;
 }
 

@@ -45,7 +45,7 @@ extern "C" int ipx_detect_chunk(ipx_ctx *ctx, const uint8_t *frames, int n, int 
     IPX_TRY(ipx_remove_bright_regions(ctx, (const uint64_t *)bright, (const uint64_t *)raw, n, H, W, (uint64_t *)raw));   // :566
     // (no keep list: the raw planes of discarded frames are all zero here, which resets the runs just the same)
     IPX_TRY(ipx_persistent_mask(ctx, (const uint64_t *)raw, nullptr, n, H, W, (uint64_t *)pers));    // :575
-    IPX_TRY(ipx_static_maps(ctx, frames, (const uint64_t *)raw, (const uint64_t *)pers, keep, n, H, W, heat, valid));   // :580-590
+    IPX_TRY(ipx_static_maps(ctx, frames, (const uint64_t *)raw, (const uint64_t *)pers, nullptr, n, H, W, heat, valid));   // :580-590
     IPX_TRY(ipx_static_from_maps(ctx, heat, valid, H, W, (uint64_t *)stat));
     IPX_TRY(ipx_finalize(ctx, frames, (const uint64_t *)raw, (const uint64_t *)pers, (const uint64_t *)stat, keep, n, H, W,
                          (uint64_t *)fin, fin3));                                                 // :592-605

@@ -48,6 +48,8 @@ struct ipx_ctx {
     void *slot[SLOT_COUNT];
     size_t slot_bytes[SLOT_COUNT];
     hipEvent_t ev0, ev1;
+    hipStream_t copy_stream;    // ipx_upload_frames: made on first use
+    hipEvent_t copy_done;
     ipx_flow_plan *flow_plan;   // cached tables for the last (H,W) seen by the flow stage
     unsigned fi_spin_limit;     // flow_iter_kernel: polls of the consumers' hand-off before it is given up (error word)
     int flow_ran;               // the flow stage has used SLOT_FLOW_RED (whose first word is its error word)

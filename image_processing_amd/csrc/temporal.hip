@@ -123,6 +123,65 @@ __global__ void static_maps_kernel(const uint8_t *frames, const uint64_t *raw, c
         }
 }
 
+// The same sums for images whose rows are multiples of 16 pixels: a thread owns 16 consecutive pixels (one 16-byte
+// load per frame, a wave reads 1 KiB of a row) of a group of SMV_GROUP <= 255 frames and keeps, per pixel, two byte
+// counters in SWAR form: heat (frames with the clean bit set) and INVALID (frame > bt and not clean).  Both are
+// sparse, so few lanes reach the atomics at the end: valid starts at n (filled by the caller) and loses the
+// invalid counts.
+constexpr int SMV_GROUP = 128;
+template <bool HAS_KEEP>
+__global__ __launch_bounds__(256) void static_maps16_kernel(const uint8_t *frames, const uint64_t *raw, const uint64_t *pers,
+                                                            const uint8_t *keep, int n, int H, int W, int wpr, int frame_gt,
+                                                            int32_t *heat, int32_t *valid)
+{
+    const int cpr = W >> 4;                                  // 16-pixel chunks per row
+    const size_t chunk = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (chunk >= (size_t)H * cpr) return;
+    const int y = (int)(chunk / cpr), xq = (int)(chunk - (size_t)y * cpr) << 4;
+    const int i0 = blockIdx.y * SMV_GROUP, i1 = min(n, i0 + SMV_GROUP);
+    const size_t words = (size_t)H * wpr, P = (size_t)H * W;
+    const size_t wi = (size_t)y * wpr + (xq >> 6);
+    const int sh = xq & 63;
+    const uint64_t notp = ~pers[wi];
+    const uint8_t *px = frames + (size_t)y * W + xq;
+    // x > frame_gt per byte, bit 7 of the byte (see swar in detect.hip): mode by the threshold's top bit
+    const int T = frame_gt;
+    const uint32_t add = (uint32_t)(0x7f - (T & 0x7f)) * 0x01010101u;
+    const bool none = T >= 255, all = T < 0, low = T < 128;
+    uint32_t hacc[4] = {0, 0, 0, 0}, iacc[4] = {0, 0, 0, 0};
+#pragma unroll 4
+    for (int i = i0; i < i1; ++i) {
+        const uint4 f = *reinterpret_cast<const uint4 *>(px + (size_t)i * P);
+        uint32_t m16 = (uint32_t)((raw[(size_t)i * words + wi] & notp) >> sh) & 0xffffu;
+        if (HAS_KEEP) m16 = keep[i] ? m16 : 0u;
+        const uint32_t d[4] = {f.x, f.y, f.z, f.w};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const uint32_t lowsum = (d[q] & 0x7f7f7f7fu) + add;
+            uint32_t g = none ? 0u : (all ? 0x80808080u : ((low ? (lowsum | d[q]) : (lowsum & d[q])) & 0x80808080u));
+            g >>= 7;                                                       // 0x01 per byte with frame > bt
+            const uint32_t ms = (((m16 >> (4 * q)) & 0xfu) * 0x00204081u) & 0x01010101u;   // clean bits, one per byte
+            hacc[q] += ms;
+            iacc[q] += g & ~ms;
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int hc = (hacc[q] >> (8 * j)) & 0xff, ic = (iacc[q] >> (8 * j)) & 0xff;
+            const size_t o = (size_t)y * W + xq + 4 * q + j;
+            if (hc) atomicAdd(&heat[o], hc);
+            if (ic) atomicSub(&valid[o], ic);
+        }
+}
+
+__global__ void fill_i32_kernel(int32_t *p, size_t count, int32_t v)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < count) p[i] = v;
+}
+
 __global__ void or_planes_kernel(const uint64_t *planes, int count, size_t words, uint64_t *out)
 {
     const size_t w = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -292,6 +351,19 @@ extern "C" int ipx_static_maps(ipx_ctx *ctx, const uint8_t *frames, const uint64
     IPX_REQUIRE(n > 0 && H > 0 && W > 0, "bad sizes");
     if (int e = ipx_ctx_enter(ctx)) return e;
     const ipx_derived d = ipx_derive(ctx->p);
+    const double ab = (double)n * ((double)H * W + (double)H * ipx_wpr(W) * 8) + 8.0 * H * W + (double)H * ipx_wpr(W) * 8;
+    if ((W & 15) == 0 && (reinterpret_cast<uintptr_t>(frames) & 15) == 0) {
+        const size_t P = (size_t)H * W, chunks = P / 16;
+        IPX_CHECK_HIP(hipMemsetAsync(heat, 0, sizeof(int32_t) * P, ctx->stream));
+        IPX_LAUNCH(ctx, KID_MISC, 4.0 * P, fill_i32_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), valid, P, (int32_t)n);
+        const dim3 g16((unsigned)((chunks + 255) / 256), (n + SMV_GROUP - 1) / SMV_GROUP), b16(256);
+        if (keep) IPX_LAUNCH(ctx, KID_STATIC_MAPS, ab, static_maps16_kernel<true>, g16, b16, frames, raw_bits, persistent_bits, keep, n, H, W,
+                             ipx_wpr(W), d.frame_gt, heat, valid);
+        else IPX_LAUNCH(ctx, KID_STATIC_MAPS, ab, static_maps16_kernel<false>, g16, b16, frames, raw_bits, persistent_bits, keep, n, H, W,
+                        ipx_wpr(W), d.frame_gt, heat, valid);
+        IPX_LAUNCH_CHECK();
+        return IPX_OK;
+    }
     const int quads = (W + 3) / 4;
     const dim3 grid((quads + 63) / 64, H, (n + SM_GROUP - 1) / SM_GROUP), block(64);
     IPX_CHECK_HIP(hipMemsetAsync(heat, 0, sizeof(int32_t) * (size_t)H * W, ctx->stream));

@@ -81,6 +81,20 @@ class Engine:
         t = torch.from_numpy(np.ascontiguousarray(a, dtype=dtype))
         return t.to(self.device, non_blocking=False)
 
+    def upload_frames(self, host_frames, out=None, register=True):
+        """ipx_upload_frames: a C-contiguous uint8 numpy array (e.g. decoder output) -> device tensor, copied on the
+        context's side stream; later calls on this engine wait for it.  ``register`` pins the array for the copy
+        (ipx_host_register) unless it already is pinned; the returned handle keeps it alive and unpins it."""
+        a = np.ascontiguousarray(host_frames, dtype=np.uint8)
+        dev = torch.empty(a.shape, dtype=torch.uint8, device=self.device) if out is None else out
+        assert dev.is_contiguous() and dev.numel() == a.size
+        pinned = False
+        if register:
+            pinned = lib.ipx_host_register(C.c_void_p(a.ctypes.data), a.nbytes) == 0
+        self._enter()
+        check(lib.ipx_upload_frames(self._ctx, C.c_void_p(a.ctypes.data), a.nbytes, _ptr(dev)))
+        return _Upload(self, dev, a, pinned)
+
     def _chk_frames(self, frames):
         assert frames.is_cuda and frames.device == self.device and frames.dtype == torch.uint8
         assert frames.dim() == 3 and frames.is_contiguous()
@@ -295,6 +309,21 @@ class Engine:
             m = self.unpack_mask(d["final_bits"], H, W).cpu().numpy().astype(bool)
             out["final_masks"] = [m[i] if keep[i] else None for i in range(n)]
         return out
+
+
+class _Upload:
+    """A pending ipx_upload_frames: ``tensor`` may be handed to any engine method right away (they wait on the
+    device); ``release()`` (after a synchronisation point of the consumer) unpins the host array."""
+
+    def __init__(self, eng, tensor, host, pinned):
+        self.eng, self.tensor, self.host, self.pinned = eng, tensor, host, pinned
+
+    def release(self):
+        if self.pinned:
+            self.eng.synchronize()
+            lib.ipx_host_unregister(C.c_void_p(self.host.ctypes.data))
+            self.pinned = False
+        self.host = None
 
 
 def _check_flows(flows):

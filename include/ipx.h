@@ -88,6 +88,17 @@ int ipx_profile_kernel_classes(void);
 int ipx_profile_read(ipx_ctx *ctx, int kernel_class, const char **name, uint64_t *launches,
                      double *total_ms, double *total_bytes);
 
+/* ---- a1 (input side): decoded frames in host memory -> HBM, ip.py:1208-1210 hands the chunk over -------------
+ * The reference keeps a chunk in host RAM; here it has to reach HBM.  ipx_upload_frames enqueues the copy on
+ * a side stream of the context (not on its compute stream: the upload of chunk k+1 runs under the kernels of
+ * chunk k) and makes every LATER call on the context wait for it.  The copy is asynchronous to the host only
+ * for pinned memory (hipHostMalloc, or any buffer passed through ipx_host_register); host_frames must stay
+ * valid, and dev_frames unused by earlier work, until the copy has run (double-buffer both).
+ * ipx_host_register / _unregister pin a caller-owned buffer (numpy arrays, decoder output). */
+int ipx_host_register(void *host, size_t bytes);
+int ipx_host_unregister(void *host);
+int ipx_upload_frames(ipx_ctx *ctx, const uint8_t *host_frames, size_t bytes, uint8_t *dev_frames);
+
 /* ---- a1: load_video_frames' grey conversion, ip.py:78-79 (cv2.cvtColor BGR2GRAY) --------- */
 int ipx_bgr2gray(ipx_ctx *ctx, const uint8_t *bgr, size_t npix, uint8_t *gray);
 

@@ -101,3 +101,46 @@ def test_write_avi_refuses_more_than_4_gb():
     frames = [np.broadcast_to(big, (4096, 4096))] * 300                 # 300 x 16 MB > 4 GB, no memory used
     with pytest.raises(ValueError, match="4 GB"):
         avi.write_avi("/nonexistent/never_written.avi", frames)
+
+
+def test_palette_of_8bit_streams_is_applied(tmp_path):
+    """An 8-bit DIB stores palette indices.  Only the identity grey ramp makes them grey levels (the fast path);
+    any other colour table is applied, as cv2 / FFmpeg do before BGR2GRAY."""
+    frames = [np.arange(24, dtype=np.uint8).reshape(4, 6) * 10 + i for i in range(3)]
+    fn = str(tmp_path / "ramp.avi")
+    avi.write_avi(fn, frames, fps=25)
+    r = avi.AviReader(fn)
+    assert r.grey_palette and r.palette.shape == (256, 3) and (r.palette[77] == 77).all()
+    r.close()
+    cap = avi.VideoCapture(fn)
+    assert cap.is_gray()
+    cap.release()
+    # the same file with an inverted, tinted colour table
+    data = bytearray(open(fn, "rb").read())
+    at = data.index(b"strf") + 8 + 40                       # colour table follows the 40-byte BITMAPINFOHEADER
+    for i in range(256):
+        data[at + 4 * i:at + 4 * i + 4] = bytes((255 - i, i // 2, i, 0))     # B, G, R, reserved
+    fn2 = str(tmp_path / "tinted.avi")
+    open(fn2, "wb").write(bytes(data))
+    r = avi.AviReader(fn2)
+    assert not r.grey_palette and r.palette[10].tolist() == [245, 5, 10]
+    assert np.array_equal(r.read(1), frames[1])             # raw indices stay available
+    r.close()
+    cap = avi.VideoCapture(fn2)
+    assert not cap.is_gray()
+    ok, f = cap.read()
+    assert ok and f.shape == (4, 6, 3)
+    assert np.array_equal(f[..., 0], 255 - frames[0]) and np.array_equal(f[..., 1], frames[0] // 2) and np.array_equal(f[..., 2], frames[0])
+    cap.release()
+
+
+def test_failed_open_leaves_nothing_open(tmp_path):
+    fn = str(tmp_path / "junk.avi")
+    open(fn, "wb").write(b"RIFF" + b"\0" * 40)
+    with pytest.raises(ValueError):
+        avi.AviReader(fn)
+    import gc
+    gc.collect()
+    import os
+    os.remove(fn)                                           # (would fail on platforms that lock mapped files)
+    assert not avi.VideoCapture(fn).isOpened()

@@ -235,3 +235,24 @@ def test_flow_handoff_timeout_is_not_silent():
         assert np.array_equal(flows.cpu().numpy(), good) and np.array_equal(keep.cpu().numpy(), good_keep)
     finally:
         eng.close()
+
+
+def test_upload_frames_side_stream_then_detect():
+    """ipx_host_register + ipx_upload_frames: host frames reach HBM on the context's side stream and the calls that
+    follow on the context see them; the result equals the one from a plain torch upload."""
+    import torch
+    from image_processing_amd import synth
+    from image_processing_amd.engine import Engine
+    frames = synth.chunk_numpy(17, 12, 72, 100, hot=9.0, stuck=2, motion_at=(5,), shift=6.0)
+    eng = Engine(0)
+    try:
+        ref = eng.detect_chunk(frames)
+        for register in (True, False):
+            up = eng.upload_frames(frames.copy(), register=register)
+            got = eng.detect_chunk(up.tensor)
+            up.release()
+            for k in ("total_counts", "cluster_counts", "avg_sizes", "avg_brightnesses", "flows", "keep"):
+                assert np.array_equal(got[k], ref[k], equal_nan=True), (register, k)
+            assert bool((up.tensor.cpu() == torch.from_numpy(frames)).all())
+    finally:
+        eng.close()

@@ -310,3 +310,59 @@ def test_load_video_frames_colour_batches(tmp_path):
     assert np.array_equal(np.stack(part), np.stack([cref.bgr2gray_u8(f) for f in bgr[30:67]]))
     raw = ip.load_video_frames(fn, grayscale=False)
     assert np.array_equal(np.stack(raw), bgr)
+
+
+def test_load_video_frames_applies_a_non_grey_palette(ip, tmp_path):
+    """An 8-bit AVI whose colour table is not the grey ramp: frames are the luma of the palette colours (what
+    cv2.VideoCapture + cvtColor return), through load_video_frames and through main's chunk loader."""
+    from image_processing_amd import avi
+    from oracle import cref
+    rng = np.random.default_rng(3)
+    idx = rng.integers(0, 256, (9, 16, 24), dtype=np.uint8)
+    fn = str(tmp_path / "ramp.avi")
+    avi.write_avi(fn, idx, fps=4.0)
+    data = bytearray(open(fn, "rb").read())
+    at = data.index(b"strf") + 8 + 40
+    pal = np.stack([255 - np.arange(256), np.arange(256) // 2, np.arange(256)], axis=1).astype(np.uint8)
+    for i in range(256):
+        data[at + 4 * i:at + 4 * i + 4] = bytes((int(pal[i, 0]), int(pal[i, 1]), int(pal[i, 2]), 0))
+    fn2 = str(tmp_path / "tinted.avi")
+    open(fn2, "wb").write(bytes(data))
+    exp = np.stack([cref.bgr2gray_u8(pal[f]) for f in idx])
+    assert np.array_equal(np.stack(ip.load_video_frames(fn2)), exp)
+    assert np.array_equal(np.stack(ip.load_video_frames(fn)), idx)              # the grey ramp: stored bytes
+    frames, pinned = ip._load_chunk(fn2, 2, 7)
+    assert np.array_equal(np.stack(frames), exp[2:7])
+
+
+def test_checkpoints_are_tied_to_video_and_settings(ip, tmp_path):
+    """A checkpoint folder reused with other settings, or for another video of the same length, must not hand back
+    the stale series; a corrupt file is recomputed and overwritten."""
+    import os
+    import warnings
+    from image_processing_amd import avi, synth
+    a = synth.chunk_numpy(21, 12, 48, 64, hot=8.0, stuck=2)
+    b = synth.chunk_numpy(22, 12, 48, 64, hot=8.0, stuck=2)
+    fa, fb = str(tmp_path / "a.avi"), str(tmp_path / "b.avi")
+    avi.write_avi(fa, list(a), fps=4.0)
+    avi.write_avi(fb, list(b), fps=4.0)
+    ck = str(tmp_path / "ck")
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        kw = dict(max_chunks=None, step_size=6)
+        ra = ip.main(fa, checkpoint_folder=ck, **kw)
+        strict = ip.main(fa, checkpoint_folder=ck, params={"brightness_threshold": 100, "consecutive_threshold": 5}, **kw)
+        fresh = ip.main(fa, params={"brightness_threshold": 100, "consecutive_threshold": 5}, **kw)
+        assert _eq_nan(strict["averages_counts"], fresh["averages_counts"])     # recomputed, not the stored series
+        assert not _eq_nan(strict["averages_counts"], ra["averages_counts"])
+        rb = ip.main(fb, checkpoint_folder=ck, **kw)                             # another video, same length, same folder
+        assert _eq_nan(rb["averages_counts"], ip.main(fb, **kw)["averages_counts"])
+        # the folder now holds b's chunks: a is recomputed again and overwrites them
+        names = sorted(os.listdir(ck))
+        with open(os.path.join(ck, names[0]), "wb") as f:
+            f.write(b"not an npz")
+        again = ip.main(fa, checkpoint_folder=ck, **kw)
+        for k in ra:
+            assert _eq_nan(again[k], ra[k]), k
+        with np.load(os.path.join(ck, names[0])) as z:                           # rewritten, readable, a's fingerprint
+            assert "a.avi" in str(z["fingerprint"])
