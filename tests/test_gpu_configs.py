@@ -79,6 +79,12 @@ def test_config3_camera_motion_heavy(eng):
     r, mid = _vs_oracle(eng, frames)
     dropped = np.flatnonzero(~r["keep"].astype(bool))
     assert set(dropped) == {4, 9, 10, 11, 20, 30, 31, 40}
+    from image_processing_amd import hostmath
+    mg = hostmath.flow_margin(r["flows"], 2.0)
+    print("config3 (jumps) flow margin:", mg)
+    # the margin is far above both the float tolerance of the metric (1e-5 relative) and the oracle/GPU difference
+    assert mg["min_margin"] > 1e-2 and mg["frames_within_rel"] == 0
+    assert np.array_equal(r["keep"].astype(bool), mid["flows"] <= 2.0)
 
 
 def test_config3_1080p_known_translations(eng):
@@ -97,6 +103,12 @@ def test_config3_1080p_known_translations(eng):
         else:
             assert np.all(np.abs(f - v) <= 0.02 * v), (v, f.min(), f.max())
     assert keep[:100].all() and not keep[100:].any()
+    # how close the motion test comes to its threshold (ip.py:559): the discard list rests on float metrics that
+    # agree with the reference's to ~1e-7 relative, so a margin of this size cannot flip a frame
+    from image_processing_amd import hostmath
+    mg = hostmath.flow_margin(flows, 2.0)
+    print("config3 flow margin:", mg)
+    assert mg["min_margin"] > 1.4 and mg["frames_within_rel"] == 0
     assert np.isnan(r["total_counts"][100:]).all() and np.isfinite(r["total_counts"][:100]).all()
     assert np.all(np.asarray(r["cluster_counts"])[100:] == 0)
 
