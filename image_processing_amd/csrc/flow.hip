@@ -625,12 +625,21 @@ struct FiArgs {
     const float *x_a, *y_b;
     unsigned *err;              // device error word of the flow stage (bit 0: a consumer hand-off timed out)
     unsigned spin_limit;        // polls a consumer wave waits for its partners before it gives up
+    int prio;                   // probe: raise the waves' issue priority
 };
 
 struct FiVec {                  // a flow vector in flight: IN 0 uses p00 only
     float2 p00, p01, p10, p11;
     float b1;
 };
+
+// the f64 value `v` of the lane whose byte address (4 * lane) is `addr`
+__device__ __forceinline__ double fi_lane_f64(double v, int addr)
+{
+    const int lo = __builtin_amdgcn_ds_bpermute(addr, __double2loint(v));
+    const int hi = __builtin_amdgcn_ds_bpermute(addr, __double2hiint(v));
+    return __hiloint2double(hi, lo);
+}
 
 // workgroup barrier that orders LDS traffic only: global loads stay in flight across it
 __device__ __forceinline__ void fi_barrier()
@@ -657,6 +666,7 @@ __global__ __launch_bounds__(FI_THREADS, 4) void flow_iter_kernel(const FiArgs a
     const int h = a.h, w = a.w, seg_rows = a.seg_rows, strips = a.strips, np = a.np, ppx = a.ppx;
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    if (a.prio) __builtin_amdgcn_s_setprio(3);
     // Workgroups go round-robin over the 8 XCDs (id % 8) and every XCD has its own L2.  XCD x gets the
     // pairs [x*ppx, (x+1)*ppx), and its resident workgroups are the same strip/segment of consecutive
     // pairs, then the neighbouring strips: the expansion of frame p+1 (sampled by pair p, read in place by
@@ -786,6 +796,8 @@ __global__ __launch_bounds__(FI_THREADS, 4) void flow_iter_kernel(const FiArgs a
                 if (c < nbch) vs[c] += (double)colb[i * FI_MROW + c * FI_MC];
         }
     }
+    const int lane_a1 = ((tid + 1) & 63) << 2, lane_a3 = ((tid + 3) & 63) << 2, lane_a5 = ((tid + 5) & 63) << 2,
+              lane_a7 = ((tid + 7) & 63) << 2;             // phase C: the lanes 1, 3, 5, 7 to the right (ds_bpermute addresses)
     int slot_in = 15;                                    // slot of row yb+7 for yb = ys
     int slot_out = 1;                                    // slot of row ys-7, the first row to leave the window
     double msum = 0.0;
@@ -891,36 +903,36 @@ __global__ __launch_bounds__(FI_THREADS, 4) void flow_iter_kernel(const FiArgs a
             // ---- C: horizontal sums + solve, row r = wave, outputs 2l, 2l+1 (l < 57)
             const int r = wave, l = tid & 63;
             const int y = yb + r;
-            if (l < FI_TW / 2 && y < ye) {
-                // window of output 2l = matrix columns 2l .. 2l+14; even columns at [l + i], odd at [HALF + l + i]
-                double acc[5];
+            if (y < ye) {
+                // Window of output 2l = matrix columns 2l .. 2l+14, of output 2l+1 = columns 2l+1 .. 2l+15; even
+                // columns at [l + i], odd at [HALF + l + i].  The 15-sums are built from sums of column pairs and
+                // quads that the lanes of the row's wave hand each other through the LDS crossbar (ds_bpermute: no
+                // LDS storage), 8 f64 additions and 13 LDS-pipe operations per channel instead of 16 and 17:
+                //   p[l] = v[2l] + v[2l+1],  q[l] = p[l] + p[l+1],  Q = q[l+1] + q[l+3] + q[l+5]  (columns 2l+2 .. 2l+13)
+                //   window(2l) = (p[l] + Q) + v[2l+14],  window(2l+1) = (v[2l+1] + Q) + p[l+7]
+                // All 64 lanes take part (lanes 57-63 only as sources; what they compute themselves is dropped).
+                double acc[2][5];
 #pragma unroll
                 for (int ch = 0; ch < 5; ++ch) {
                     const double *ve = s_v + ch * (FI_G * FI_MC) + r * FI_MC + l;
-                    const double *vd = ve + FI_HALF;
-                    double s = ve[0];
-#pragma unroll
-                    for (int i = 1; i <= FI_M; ++i) s += vd[i - 1] + ve[i];
-                    acc[ch] = s;
+                    const double v0 = ve[0], v1 = ve[FI_HALF], v14 = ve[FI_M];
+                    const double pr = v0 + v1;
+                    const double q = pr + fi_lane_f64(pr, lane_a1);
+                    const double Q = (fi_lane_f64(q, lane_a1) + fi_lane_f64(q, lane_a3)) + fi_lane_f64(q, lane_a5);
+                    acc[0][ch] = (pr + Q) + v14;
+                    acc[1][ch] = (v1 + Q) + fi_lane_f64(pr, lane_a7);
                 }
                 const double scale = 1.0 / (double)((2 * FI_M + 1) * (2 * FI_M + 1));
                 float2 o[2];
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
-                    if (j == 1) {                        // slide the window by one column: + column 2l+15, - column 2l
-#pragma unroll
-                        for (int ch = 0; ch < 5; ++ch) {
-                            const double *ve = s_v + ch * (FI_G * FI_MC) + r * FI_MC + l;
-                            acc[ch] += ve[FI_HALF + FI_M] - ve[0];
-                        }
-                    }
-                    const double g11 = acc[0] * scale, g12 = acc[1] * scale, g22 = acc[2] * scale,
-                                 h1 = acc[3] * scale, h2 = acc[4] * scale;
+                    const double g11 = acc[j][0] * scale, g12 = acc[j][1] * scale, g22 = acc[j][2] * scale,
+                                 h1 = acc[j][3] * scale, h2 = acc[j][4] * scale;
                     const double idet = 1. / (g11 * g22 - g12 * g12 + 1e-3);
                     o[j].x = (float)((g11 * h2 - g12 * h1) * idet);
                     o[j].y = (float)((g22 * h1 - g12 * h2) * idet);
                 }
-                const int x = x0 + 2 * l;
+                const int x = l < FI_TW / 2 ? x0 + 2 * l : w;     // lanes 57-63 own no output
                 if (REDUCE) {
                     if (x < w) msum += (double)sqrtf(o[0].x * o[0].x + o[0].y * o[0].y);      // cartToPolar magnitude in f32
                     if (x + 1 < w) msum += (double)sqrtf(o[1].x * o[1].x + o[1].y * o[1].y);
@@ -971,6 +983,77 @@ __global__ void first_frame_kernel(float *flows, uint8_t *keep)
 {
     flows[0] = 0.f;                                        // ip.py:853: optical_flows[0] = 0
     if (keep) keep[0] = 1;
+}
+
+// Overlap probe (debug, IPX_FI_OVERLAP_PROBE=<workgroups>[,<iterations>]): an LDS-free kernel of pure vector
+// arithmetic (8 independent f32 chains, 48 registers at most) that run_pairs puts on a side stream beside the
+// level-0 iterations, to measure how much arithmetic the memory-bound marching kernel leaves room for on the
+// same CUs (its two workgroups hold 158.7 of the CU's 160 KB of LDS: only kernels without LDS can join them).
+__global__ __launch_bounds__(256) void fi_probe_burn_kernel(int iters, float *sink)
+{
+    float a0 = threadIdx.x, a1 = a0 + 1.f, a2 = a0 + 2.f, a3 = a0 + 3.f, a4 = a0 + 4.f, a5 = a0 + 5.f, a6 = a0 + 6.f, a7 = a0 + 7.f;
+    const float m = 1.0000001f, c = 1e-7f;
+#pragma unroll 1
+    for (int i = 0; i < iters; ++i) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            a0 = __builtin_fmaf(a0, m, c); a1 = __builtin_fmaf(a1, m, c); a2 = __builtin_fmaf(a2, m, c); a3 = __builtin_fmaf(a3, m, c);
+            a4 = __builtin_fmaf(a4, m, c); a5 = __builtin_fmaf(a5, m, c); a6 = __builtin_fmaf(a6, m, c); a7 = __builtin_fmaf(a7, m, c);
+        }
+    }
+    const float s = ((a0 + a1) + (a2 + a3)) + ((a4 + a5) + (a6 + a7));
+    if (s == 12345.678f) sink[0] = s;                      // never true: keeps the chains alive
+}
+
+// the same with f64 chains (add, fma, or convert + add), to measure the issue rate of the f64 instructions the consumers use
+template <int KIND>
+__global__ __launch_bounds__(256) void fi_probe_burn64_kernel(int iters, float *sink)
+{
+    double a0 = threadIdx.x, a1 = a0 + 1., a2 = a0 + 2., a3 = a0 + 3., a4 = a0 + 4., a5 = a0 + 5., a6 = a0 + 6., a7 = a0 + 7.;
+    const double m = 1.0000001, c = 1e-7;
+    float f = (float)threadIdx.x;
+#pragma unroll 1
+    for (int i = 0; i < iters; ++i) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (KIND == 0) { a0 += c; a1 += c; a2 += c; a3 += c; a4 += c; a5 += c; a6 += c; a7 += c; }
+            else if (KIND == 1) {
+                a0 = __builtin_fma(a0, m, c); a1 = __builtin_fma(a1, m, c); a2 = __builtin_fma(a2, m, c); a3 = __builtin_fma(a3, m, c);
+                a4 = __builtin_fma(a4, m, c); a5 = __builtin_fma(a5, m, c); a6 = __builtin_fma(a6, m, c); a7 = __builtin_fma(a7, m, c);
+            } else {
+                a0 += (double)f; f += 1.f; a1 += (double)f; f += 1.f; a2 += (double)f; f += 1.f; a3 += (double)f; f += 1.f;
+            }
+        }
+    }
+    const double s = ((a0 + a1) + (a2 + a3)) + ((a4 + a5) + (a6 + a7));
+    if (s == 12345.678) sink[0] = (float)s;
+}
+
+struct FiProbe { int wgs, iters; hipStream_t side; hipEvent_t fork, join, b0, b1; bool ready; };
+FiProbe *fi_probe()
+{
+    static FiProbe pr = {0, 0, nullptr, nullptr, nullptr, nullptr, nullptr, false};
+    static bool parsed = false;
+    if (!parsed) {
+        parsed = true;
+        const char *e = getenv("IPX_FI_OVERLAP_PROBE");
+        if (e && *e) {
+            pr.wgs = atoi(e);
+            const char *c = strchr(e, ',');
+            pr.iters = c ? atoi(c + 1) : 20000;
+        }
+    }
+    if (pr.wgs <= 0) return nullptr;
+    if (!pr.ready) {
+        int plo = 0, phi = 0;
+        (void)hipDeviceGetStreamPriorityRange(&plo, &phi);          // plo = lowest priority (largest number)
+        if (hipStreamCreateWithPriority(&pr.side, hipStreamNonBlocking, getenv("IPX_FI_SIDE_LOW") ? plo : 0) != hipSuccess) return nullptr;
+        (void)hipEventCreateWithFlags(&pr.fork, hipEventDisableTiming);
+        (void)hipEventCreateWithFlags(&pr.join, hipEventDisableTiming);
+        (void)hipEventCreate(&pr.b0); (void)hipEventCreate(&pr.b1);
+        pr.ready = true;
+    }
+    return &pr;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1185,6 +1268,22 @@ int run_pairs(ipx_ctx *ctx, const uint8_t *frames, const uint8_t *extra, int fir
         a.h = g.lh; a.w = g.lw; a.seg_rows = f.seg_rows; a.strips = f.strips; a.nseg = f.nseg; a.np = np; a.ppx = f.ppx;
         a.sh = a.sw = 0; a.x_ofs = a.y_ofs = nullptr; a.x_a = a.y_b = nullptr;
         a.err = err; a.spin_limit = ctx->fi_spin_limit;
+        a.prio = getenv("IPX_FI_PRIO") != nullptr;
+        FiProbe *probe = k == 0 ? fi_probe() : nullptr;
+        const bool probe_alone = probe && getenv("IPX_FI_OVERLAP_ALONE") != nullptr;   // the burn without the iterations beside it
+        if (probe) {
+            (void)hipEventRecord(probe->fork, ctx->stream);
+            (void)hipStreamWaitEvent(probe->side, probe->fork, 0);
+            (void)hipEventRecord(probe->b0, probe->side);
+            const char *k64 = getenv("IPX_FI_OVERLAP_F64");
+            if (!k64) hipLaunchKernelGGL(fi_probe_burn_kernel, dim3(probe->wgs), dim3(256), 0, probe->side, probe->iters, (float *)uv);
+            else if (k64[0] == '0') hipLaunchKernelGGL(fi_probe_burn64_kernel<0>, dim3(probe->wgs), dim3(256), 0, probe->side, probe->iters, (float *)uv);
+            else if (k64[0] == '1') hipLaunchKernelGGL(fi_probe_burn64_kernel<1>, dim3(probe->wgs), dim3(256), 0, probe->side, probe->iters, (float *)uv);
+            else hipLaunchKernelGGL(fi_probe_burn64_kernel<2>, dim3(probe->wgs), dim3(256), 0, probe->side, probe->iters, (float *)uv);
+            (void)hipEventRecord(probe->b1, probe->side);
+            (void)hipEventRecord(probe->join, probe->side);
+            if (probe_alone) (void)hipStreamWaitEvent(ctx->stream, probe->join, 0);
+        }
         for (int it = 0; it < 3; ++it) {                            // ip.py:864 iterations=3
             a.flow_in = cur; a.flow_out = other;
             const bool reduce = !uv_out && k == 0 && it == 2;
@@ -1205,6 +1304,14 @@ int run_pairs(ipx_ctx *ctx, const uint8_t *frames, const uint8_t *extra, int fir
                 IPX_LAUNCH_LDS(ctx, KID_FLOW_ITER, bytes, FI_LDS_BYTES, (flow_iter_kernel<2, false>), fgrid, fblock, a);
             }
             float2 *t = cur; cur = other; other = t;
+        }
+        if (probe) {
+            if (!probe_alone) (void)hipStreamWaitEvent(ctx->stream, probe->join, 0);
+            (void)hipEventSynchronize(probe->join);
+            float ms = 0.f;
+            (void)hipEventElapsedTime(&ms, probe->b0, probe->b1);
+            fprintf(stderr, "[fi probe] burn %d workgroups x %d iterations: %.3f ms (%s the level-0 iterations)\n", probe->wgs, probe->iters, ms,
+                    probe_alone ? "before" : "beside");
         }
         IPX_LAUNCH_CHECK();
     }

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """One stage of the path alone on a resident 1080p chunk (for rocprofv3 --pmc passes and quick A/B timing):
-    python tools/bench_stage.py detect|temporal [frames] [reps]
+    python tools/bench_stage.py detect|temporal|flow [frames] [reps]
 Prints the built-in profiler's per-kernel table for the stage."""
 import os
 import sys
@@ -21,6 +21,17 @@ def main():
     eng = Engine(0)
     fr = synth.chunk_torch(2, n, H, W, dev)
     keep = torch.ones(n, dtype=torch.uint8, device=dev)
+    if stage == "flow":                       # the motion test alone: wall time per call (events on the launch stream)
+        eng.flow_metric(fr)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        for _ in range(reps):
+            e0.record()
+            eng.flow_metric(fr)
+            e1.record()
+            torch.cuda.synchronize()
+            print("flow_metric(%d frames): %.3f ms" % (n, e0.elapsed_time(e1)), flush=True)
+        return
     raw, bright, dense = eng.detect_raw(fr, keep)
     eng.remove_bright_regions(bright, raw, H, W, out=raw)
     torch.cuda.synchronize()
