@@ -87,6 +87,11 @@ PROTOTYPES = {
     "ipx_dense_counts": (_i, [_ctx, _p, _i, _i, _i, _p]),
     "ipx_cluster_stats": (_i, [_ctx, _p, _p, _p, _i, _i, _i, _p, _i, _p, _p]),
     "ipx_detect_chunk": (_i, [_ctx, _p, _i, _i, _i, _p, _i, _p, _p, _p, _p, _p]),
+    "ipx_group_create": (_i, [_p, _i, _i, C.POINTER(_p)]),
+    "ipx_group_destroy": (_i, [_p]),
+    "ipx_group_set_params": (_i, [_p, C.POINTER(Params)]),
+    "ipx_group_info": (_i, [_p, C.POINTER(_i), C.POINTER(_i)]),
+    "ipx_group_detect_chunk": (_i, [_p, _p, _i, _i, _i, _p, _i, _p, _p, _p, _p]),
     "ipx_pack_mask": (_i, [_ctx, _p, _i, _i, _i, _p]),
     "ipx_unpack_mask": (_i, [_ctx, _p, _i, _i, _i, _p]),
 }

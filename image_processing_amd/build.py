@@ -15,7 +15,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libipx.so")
-SOURCES = ["api.hip", "detect.hip", "temporal.hip", "ccl.hip", "flow.hip", "chunk.hip"]
+SOURCES = ["api.hip", "detect.hip", "temporal.hip", "ccl.hip", "flow.hip", "chunk.hip", "group.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
          "-fvisibility=hidden", "-Wall", "-Wno-unused-result"]
 
@@ -82,7 +82,7 @@ def build_lib(force=False, verbose=False):
                 if os.path.exists(o):
                     os.remove(o)
             raise
-        cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+        cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-ldl", "-lpthread"]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)

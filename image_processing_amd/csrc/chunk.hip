@@ -20,6 +20,15 @@ __global__ void merge_counts_kernel(const int64_t *fin3, const int64_t *dense2, 
 
 }  // namespace
 
+// (internal: also the last step of a rank of ipx_group_detect_chunk, group.hip)
+int ipx_merge_counts(ipx_ctx *ctx, const int64_t *fin3, const int64_t *dense2, int n, int64_t *out5)
+{
+    IPX_TRY(ipx_ctx_enter(ctx));
+    IPX_LAUNCH(ctx, KID_MISC, 80.0 * n, merge_counts_kernel, dim3((n + 255) / 256), dim3(256), fin3, dense2, n, out5);
+    IPX_LAUNCH_CHECK();
+    return IPX_OK;
+}
+
 extern "C" int ipx_detect_chunk(ipx_ctx *ctx, const uint8_t *frames, int n, int H, int W,
                                 const double *pow2_table, int tdim,
                                 float *flows, uint8_t *keep, int64_t *counts, int64_t *cluster,
@@ -50,7 +59,5 @@ extern "C" int ipx_detect_chunk(ipx_ctx *ctx, const uint8_t *frames, int n, int 
     IPX_TRY(ipx_finalize(ctx, frames, (const uint64_t *)raw, (const uint64_t *)pers, (const uint64_t *)stat, keep, n, H, W,
                          (uint64_t *)fin, fin3));                                                 // :592-605
     IPX_TRY(ipx_cluster_stats(ctx, frames, (const uint64_t *)fin, keep, n, H, W, pow2_table, tdim, cluster, nullptr));   // :608
-    IPX_LAUNCH(ctx, KID_MISC, 80.0 * n, merge_counts_kernel, dim3((n + 255) / 256), dim3(256), fin3, dense2, n, counts);
-    IPX_LAUNCH_CHECK();
-    return IPX_OK;
+    return ipx_merge_counts(ctx, fin3, dense2, n, counts);
 }

@@ -16,7 +16,8 @@ enum ipx_slot {
     SLOT_FLOW_PYR,       // flow.hip: level images + polynomial expansions of a batch
     SLOT_FLOW_UV,        // flow.hip: flow fields (two levels, ping-pong)
     SLOT_FLOW_RED,       // flow.hip: partial sums of the magnitude reduction
-    WS_RAW, WS_BRIGHT, WS_PERS, WS_STATIC, WS_FINAL, WS_MAPS, WS_COUNTS,   // chunk.hip
+    WS_RAW, WS_BRIGHT, WS_PERS, WS_STATIC, WS_FINAL, WS_MAPS, WS_COUNTS,   // chunk.hip (and the ranks of group.hip)
+    GS_FRAMES, GS_MISC, GS_EDGES, GS_PERS_ALL, GS_MAPS_ALL,                // group.hip: a rank's frames, small arrays, exchange areas
     SLOT_COUNT
 };
 

@@ -311,6 +311,67 @@ class Engine:
         return out
 
 
+class Group:
+    """ipx_group_*: one chunk sharded by frame range across several GPUs INSIDE libipx (one host thread, context and
+    stream per device; exchanges over RCCL or peer copies).  The C-level counterpart of sharding.py, for callers
+    that are one process: ``Group([0, 1, 2, 3]).detect_chunk(frames)`` returns what ``Engine.detect_chunk`` returns
+    for the whole chunk.  ``devices`` may repeat a device with transport "peer" (tests on a one-GPU box)."""
+
+    TRANSPORTS = {"auto": 0, "peer": 1, "rccl": 2}
+
+    def __init__(self, devices, params=None, transport="auto"):
+        if not torch.cuda.is_available():
+            raise RuntimeError("image_processing_amd needs a ROCm GPU (MI355X); there is no CPU fallback")
+        devs = [int(d) for d in devices]
+        arr = (C.c_int * len(devs))(*devs)
+        self._g = C.c_void_p()
+        check(lib.ipx_group_create(arr, len(devs), self.TRANSPORTS[transport], C.byref(self._g)))
+        nd, tr = C.c_int(), C.c_int()
+        check(lib.ipx_group_info(self._g, C.byref(nd), C.byref(tr)))
+        self.devices, self.transport = devs, {v: k for k, v in self.TRANSPORTS.items()}[tr.value]
+        self.params = None
+        self.set_params(params)
+
+    def set_params(self, params=None):
+        p = _ipx.default_params()
+        d = dict(params or {})
+        d.pop("number_of_plots", None)
+        for k, v in d.items():
+            if not hasattr(p, k):
+                raise KeyError("unknown setting %r" % (k,))
+            setattr(p, k, v)
+        self.params = p
+        check(lib.ipx_group_set_params(self._g, C.byref(p)))
+        self._pow2, self._pow2_dim = hostmath.pow2_table(int(p.max_cluster_size))
+
+    def close(self):
+        if self._g:
+            lib.ipx_group_destroy(self._g)
+            self._g = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def detect_chunk(self, frames):
+        """frames: (n,H,W) uint8 numpy array in host memory -> the dict of Engine.detect_chunk (without masks)."""
+        a = np.ascontiguousarray(frames, dtype=np.uint8)
+        n, H, W = a.shape
+        flows = np.empty(n, dtype=np.float32)
+        keep = np.empty(n, dtype=np.uint8)
+        counts = np.empty((n, 5), dtype=np.int64)
+        cluster = np.empty((n, 3), dtype=np.int64)
+        tab = np.ascontiguousarray(self._pow2, dtype=np.float64)
+        vp = lambda x: C.c_void_p(x.ctypes.data)
+        check(lib.ipx_group_detect_chunk(self._g, vp(a), n, H, W, vp(tab), self._pow2_dim, vp(flows), vp(keep), vp(counts),
+                                         vp(cluster)))
+        total, cc, cs, cb = hostmath.chunk_results(keep, counts, cluster, H * W)
+        return dict(total_counts=total, cluster_counts=cc, avg_sizes=cs, avg_brightnesses=cb,
+                    flows=_check_flows(flows.astype(np.float64)), keep=keep, counts=counts, cluster=cluster)
+
+
 class _Upload:
     """A pending ipx_upload_frames: ``tensor`` may be handed to any engine method right away (they wait on the
     device); ``release()`` (after a synchronisation point of the consumer) unpins the host array."""

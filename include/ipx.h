@@ -223,6 +223,33 @@ int ipx_detect_chunk(ipx_ctx *ctx, const uint8_t *frames, int n, int H, int W,
                      float *flows, uint8_t *keep, int64_t *counts, int64_t *cluster,
                      uint64_t *final_bits);
 
+/* ---- a18 across the GPUs of a node (BASELINE configs[2]; no counterpart in the single-process reference, whose
+ * unit of work is the chunk, ip.py:1204-1227) ------------------------------------------------------------------
+ * A group owns one context, one stream and one host thread per listed device.  ipx_group_detect_chunk takes the
+ * chunk in HOST memory (as the reference holds it), shards it by frame range (rank r owns frames
+ * [r n / ndev, (r+1) n / ndev) and uploads them plus `sliding_window_radius` halo frames each side), runs the stages
+ * of ipx_detect_chunk on every shard and exchanges what crosses a shard boundary: the T-1 edge planes and the
+ * persistence maps (ip.py:270-289) and the chunk-wide heat / valid maps (ip.py:451-459).  Results are identical to
+ * ipx_detect_chunk on the whole chunk, bit for bit (the metric of a shard's first frame included: it is computed
+ * against the left halo frame), and are written to the caller's HOST arrays: flows float32 [n], keep uint8 [n],
+ * counts int64 [n][5], cluster int64 [n][3] (layouts of ipx_detect_chunk); pow2_table_host as there, but in host
+ * memory.  The call returns when all ranks are done.  Every rank needs at least max(consecutive_threshold-1, 1)
+ * frames.  transport: IPX_GROUP_RCCL = ncclAllGather / ncclAllReduce on an ncclCommInitAll communicator (librccl
+ * is loaded at run time; devices must be distinct; a group of one still runs its collectives), IPX_GROUP_PEER =
+ * hipMemcpyPeerAsync between the ranks' buffers (a device may be listed more than once), IPX_GROUP_AUTO = RCCL
+ * for two or more distinct devices when librccl loads, else peer copies.  devices == NULL means 0 .. ndev-1. */
+typedef struct ipx_group ipx_group;
+#define IPX_GROUP_AUTO 0
+#define IPX_GROUP_PEER 1
+#define IPX_GROUP_RCCL 2
+int ipx_group_create(const int *devices, int ndev, int transport, ipx_group **out);
+int ipx_group_destroy(ipx_group *g);
+int ipx_group_set_params(ipx_group *g, const ipx_params *p);
+int ipx_group_info(const ipx_group *g, int *ndev, int *transport);
+int ipx_group_detect_chunk(ipx_group *g, const uint8_t *frames_host, int n, int H, int W,
+                           const double *pow2_table_host, int tdim,
+                           float *flows_host, uint8_t *keep_host, int64_t *counts_host, int64_t *cluster_host);
+
 /* ---- helpers: host<->device packing used by the Python stage wrappers ----------------------- */
 int ipx_pack_mask(ipx_ctx *ctx, const uint8_t *mask, int count, int H, int W, uint64_t *bits);
 int ipx_unpack_mask(ipx_ctx *ctx, const uint64_t *bits, int count, int H, int W, uint8_t *mask);

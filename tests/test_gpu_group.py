@@ -1,0 +1,87 @@
+"""ipx_group_* (include/ipx.h): the frame-range sharding of one chunk INSIDE libipx -- one host thread, context and
+stream per rank -- must equal ipx_detect_chunk on the whole chunk bit for bit.  On the one-GPU box the ranks of the
+peer-copy transport all sit on device 0 (the sharding logic, halos, edge planes, OR / sum merges are the same code as
+with distinct devices); the RCCL transport is exercised as a world of one, which still sends every exchange through
+ncclAllGather / ncclAllReduce."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+KEYS = ("total_counts", "cluster_counts", "avg_sizes", "avg_brightnesses", "keep", "counts", "cluster")
+
+
+def _frames(seed, n, h, w):
+    from image_processing_amd import synth
+    fr = synth.chunk_numpy(seed, n, h, w, hot=14.0, stuck=3, motion_at=(6, 11), shift=6.0)
+    fr[3:6, 4, 9] = 255
+    fr[8:12, 20, 30] = 255
+    fr[:, 40:44, 60:64] = 250          # a static bright block: exercises the chunk-wide static map
+    return fr
+
+
+def _same(a, b):
+    for k in KEYS:
+        assert np.array_equal(np.asarray(a[k]), np.asarray(b[k]), equal_nan=True), k
+    assert np.array_equal(a["flows"], b["flows"]), "flows"
+
+
+@pytest.mark.parametrize("world,n,params", [
+    (1, 12, None),
+    (2, 20, None),
+    (3, 19, dict(consecutive_threshold=3, sliding_window_radius=2, static_threshold=20)),
+    (4, 16, dict(consecutive_threshold=4, sliding_window_radius=5)),
+    (2, 9, dict(consecutive_threshold=1)),
+    (5, 41, dict(consecutive_threshold=2, sliding_window_radius=1, flow_threshold=0.4)),
+])
+def test_group_peer_equals_whole_chunk(world, n, params):
+    from image_processing_amd.engine import Engine, Group
+    fr = _frames(7 + world, n, 90, 150)
+    ref = Engine(0, params).detect_chunk(fr)
+    g = Group([0] * world, params, transport="peer")
+    assert g.transport == "peer"
+    _same(g.detect_chunk(fr), ref)
+    _same(g.detect_chunk(fr), ref)                     # a second call on the same buffers
+    fr2 = _frames(70 + world, n + 3, 64, 100)          # then another geometry through the same group
+    _same(g.detect_chunk(fr2), Engine(0, params).detect_chunk(fr2))
+    g.close()
+
+
+def test_group_rccl_world_of_one():
+    from image_processing_amd.engine import Engine, Group
+    params = dict(consecutive_threshold=3, sliding_window_radius=2)
+    fr = _frames(3, 18, 90, 150)
+    ref = Engine(0, params).detect_chunk(fr)
+    g = Group([0], params, transport="rccl")
+    assert g.transport == "rccl"
+    _same(g.detect_chunk(fr), ref)
+    g.close()
+
+
+def test_group_auto_and_errors():
+    from image_processing_amd import _ipx
+    from image_processing_amd.engine import Group
+    g = Group([0], transport="auto")
+    assert g.transport == "peer"                       # one device: nothing to exchange, RCCL is not loaded
+    g.close()
+    with pytest.raises(_ipx.IpxError):                 # RCCL refuses a device listed twice
+        Group([0, 0], transport="rccl")
+    with pytest.raises(_ipx.IpxError):
+        Group([99])
+    g = Group([0, 0, 0], dict(consecutive_threshold=4), transport="peer")
+    with pytest.raises(_ipx.IpxError, match="every rank needs"):
+        g.detect_chunk(_frames(1, 8, 32, 48))          # 8 frames over 3 ranks: fewer than T-1 = 3 per rank
+    g.close()
+
+
+def test_group_full_size_shards():
+    """1080p, 96 frames over 4 ranks on device 0: the sizes of the real workload (one strip per 114 columns, 128 x 64
+    detect tiles, 17 + 9 words per row) through the group path."""
+    from image_processing_amd import synth
+    from image_processing_amd.engine import Engine, Group
+    import torch
+    fr = synth.chunk_torch(5, 96, 1080, 1920, torch.device("cuda", 0)).cpu().numpy()
+    ref = Engine(0).detect_chunk(fr)
+    g = Group([0, 0, 0, 0], transport="peer")
+    _same(g.detect_chunk(fr), ref)
+    g.close()
