@@ -85,3 +85,20 @@ def test_group_full_size_shards():
     g = Group([0, 0, 0, 0], transport="peer")
     _same(g.detect_chunk(fr), ref)
     g.close()
+
+
+def test_group_randomised_sweep():
+    """tools/fuzz_sharded.py --group: random world sizes (1-6), chunk lengths down to the minimum a rank may hold,
+    window radii up to 8, persistence thresholds 1-4 (3000 cases passed on the GPU box; 60 here)."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import fuzz_sharded
+    from image_processing_amd.engine import Engine
+    eng, groups = Engine(0), {}
+    try:
+        for seed in range(9000, 9060):
+            assert fuzz_sharded.group_case(eng, groups, seed).startswith("ok")
+    finally:
+        for g in groups.values():
+            g.close()

@@ -2,7 +2,9 @@
 """Randomised check of frame-range sharding: the shards of a random chunk run as threads on one GPU (one
 libipx context each, an in-process stand-in for the process group) and must reproduce ipx_detect_chunk on
 the whole chunk bit for bit (flows included), for random world sizes, chunk lengths and parameter sets.
-    python tools/fuzz_sharded.py [cases] [seed]"""
+    python tools/fuzz_sharded.py [cases] [seed] [--group]
+--group: the same cases through ipx_group_detect_chunk instead (the sharding done inside libipx, all ranks on GPU 0,
+peer-copy transport)."""
 import os
 import sys
 import threading
@@ -64,15 +66,47 @@ def one_case(engines, seed):
     return "ok  world=%d n=%-2d %3dx%-3d T=%d r=%d kept=%d counts=%d" % (world, n, w, h, T, radius, int(ref["keep"].sum()), int(ref["counts"][:, 0].sum()))
 
 
+def group_case(engine, groups, seed):
+    """One random case through the C-level group (ranks = contexts on GPU 0)."""
+    from image_processing_amd import synth
+    from image_processing_amd.engine import Group
+    rng = np.random.default_rng(seed)
+    world = int(rng.integers(1, 7))
+    T = int(rng.integers(1, 5)); radius = int(rng.integers(1, 9))
+    n = int(rng.integers(max(world * max(T - 1, 1), 2), 48))
+    h = int(rng.integers(34, 120)); w = int(rng.integers(34, 200))
+    params = dict(consecutive_threshold=T, sliding_window_radius=radius, brightness_threshold=int(rng.integers(120, 220)),
+                  flow_threshold=float(rng.choice([0.5, 2.0, 4.0])), static_threshold=float(rng.choice([5, 20, 50])),
+                  max_cluster_size=int(rng.integers(6, 40)))
+    motion = tuple(int(x) for x in rng.choice(np.arange(1, n), size=min(int(rng.integers(0, 4)), n - 1), replace=False)) if n > 2 else ()
+    frames = synth.chunk_numpy(seed, n, h, w, hot=float(rng.uniform(2, 30)), stuck=int(rng.integers(0, 6)),
+                               motion_at=motion, shift=float(rng.uniform(0.5, 9)), blobs=int(rng.integers(0, 4)))
+    for k in range(int(rng.integers(0, 4))):
+        s = int(rng.integers(0, n)); frames[s:s + int(rng.integers(1, 6)), int(rng.integers(0, h)), int(rng.integers(0, w))] = 255
+    engine.set_params(params)
+    ref = engine.detect_chunk(frames)
+    if world not in groups:
+        groups[world] = Group([0] * world, transport="peer")
+    g = groups[world]
+    g.set_params(params)
+    out = g.detect_chunk(frames)
+    for k in ("flows", "keep", "counts", "cluster", "total_counts", "cluster_counts", "avg_sizes", "avg_brightnesses"):
+        assert np.array_equal(np.asarray(out[k]), np.asarray(ref[k]), equal_nan=True), k
+    return "ok  group world=%d n=%-2d %3dx%-3d T=%d r=%d kept=%d counts=%d" % (world, n, w, h, T, radius, int(ref["keep"].sum()), int(ref["counts"][:, 0].sum()))
+
+
 def main():
     from image_processing_amd.engine import Engine
-    cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
-    seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 500
-    engines = [Engine(0) for _ in range(5)]
+    args = [a for a in sys.argv[1:] if not a.startswith("--")]
+    group = "--group" in sys.argv
+    cases = int(args[0]) if len(args) > 0 else 40
+    seed0 = int(args[1]) if len(args) > 1 else 500
+    engines = [Engine(0) for _ in range(1 if group else 5)]
+    groups = {}
     t0 = time.time()
     for k in range(cases):
         try:
-            msg = one_case(engines, seed0 + k)
+            msg = group_case(engines[0], groups, seed0 + k) if group else one_case(engines, seed0 + k)
         except AssertionError as e:
             print("seed %d: MISMATCH %s" % (seed0 + k, e), flush=True)
             sys.exit(1)
