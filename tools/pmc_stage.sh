@@ -2,15 +2,16 @@
 # PMC passes over one stage: tools/pmc_stage.sh <tag> <stage> "<counters pass 1>" ["<counters pass 2>" ...]  (on the GPU box)
 set -e
 tag=$1; stage=$2; shift 2
-root=$(pwd); out=$root/gpurun_out
+root=$(pwd); out=$root/gpurun_out; raw=/tmp/ipx_pmc_$tag   # raw counter files stay off gpurun_out (64 MiB limit)
+mkdir -p $raw
 export TMPDIR=/tmp
 cd /tmp
 i=0
 for ctr in "$@"; do
     i=$((i+1))
-    timeout -s KILL 120 rocprofv3 --pmc $ctr --output-format csv -d $out/${tag}_pmc$i -o ${tag} -- \
+    timeout -s KILL 120 rocprofv3 --pmc $ctr --output-format csv -d $raw/pmc$i -o ${tag} -- \
         python3 $root/tools/bench_stage.py $stage 1000 1 > $out/${tag}_pmc$i.log 2>&1
-    python3 - "$out/${tag}_pmc$i" <<'PY'
+    python3 - "$raw/pmc$i" <<'PY'
 import csv, sys, collections, glob
 acc = collections.defaultdict(lambda: [0, 0.0])
 for p in glob.glob(sys.argv[1] + "/**/*counter_collection.csv", recursive=True):
