@@ -439,10 +439,18 @@ __global__ __launch_bounds__(256) void detect_kernel(DetectArgs a)
     const bool interior = x0 - 16 >= 0 && x0 + TW + 16 <= W && y0 - AX >= 0 && y0 - AX + WIN_H <= H;
     if (interior && (W & 15) == 0 && (reinterpret_cast<uintptr_t>(a.frames) & 15) == 0) {
         const uint8_t *base = frame + (size_t)(y0 - AX) * W + x0 - 16;
-        for (int idx = tid; idx < WIN_H * (WIN_W / 16); idx += 256) {
-            const int r = idx / (WIN_W / 16), q = idx - r * (WIN_W / 16);
-            const uint4 v = *reinterpret_cast<const uint4 *>(base + (size_t)r * W + 16 * q);
-            *reinterpret_cast<uint4 *>(s_win + r * WIN_STRIDE + 16 * q) = v;
+        // all of a thread's loads are issued before the first is stored (a rolled loop waits for each load in turn)
+        constexpr int NIT = (WIN_H * (WIN_W / 16) + 255) / 256;
+        uint4 v[NIT];
+#pragma unroll
+        for (int k = 0; k < NIT; ++k) {
+            const int idx = tid + 256 * k, r = idx / (WIN_W / 16), q = idx - r * (WIN_W / 16);
+            if (idx < WIN_H * (WIN_W / 16)) v[k] = *reinterpret_cast<const uint4 *>(base + (size_t)r * W + 16 * q);
+        }
+#pragma unroll
+        for (int k = 0; k < NIT; ++k) {
+            const int idx = tid + 256 * k, r = idx / (WIN_W / 16), q = idx - r * (WIN_W / 16);
+            if (idx < WIN_H * (WIN_W / 16)) *reinterpret_cast<uint4 *>(s_win + r * WIN_STRIDE + 16 * q) = v[k];
         }
     } else {
         const bool interior_x = aligned && x0 - 16 >= 0 && x0 + TW + 16 <= W;

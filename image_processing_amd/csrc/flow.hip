@@ -423,13 +423,26 @@ __global__ __launch_bounds__(256) void polyexp_kernel(const float *I, int h, int
     const int ty = rem / tiles_x, tx = rem - ty * tiles_x;
     const int x0 = tx * PX_TW, y0 = ty * PX_TH;
     const float *img = I + (size_t)f * h * w;
-    // 1. window
-    for (int i = tid; i < PX_SH * PX_SW; i += 256) {
-        const int r = i / PX_SW, c = i - r * PX_SW;
-        int y = y0 - POLY_N + r, x = x0 - POLY_N + c;
-        y = y < 0 ? 0 : (y > h - 1 ? h - 1 : y);
-        x = x < 0 ? 0 : (x > w - 1 ? w - 1 : x);
-        s_in[r * PX_SP + c] = img[(size_t)y * w + x];
+    // 1. window: all of a thread's loads are issued before the first is stored (a rolled loop waits for every load
+    // before it issues the next: eight serial trips to memory per tile)
+    {
+        constexpr int NIT = (PX_SH * PX_SW + 255) / 256;
+        float v[NIT];
+#pragma unroll
+        for (int k = 0; k < NIT; ++k) {
+            const int i = tid + 256 * k;
+            const int r = i / PX_SW, c = i - r * PX_SW;
+            int y = y0 - POLY_N + r, x = x0 - POLY_N + c;
+            y = y < 0 ? 0 : (y > h - 1 ? h - 1 : y);
+            x = x < 0 ? 0 : (x > w - 1 ? w - 1 : x);
+            v[k] = i < PX_SH * PX_SW ? img[(unsigned)(y * w + x)] : 0.f;     // a level image has fewer than 2^26 pixels
+        }
+#pragma unroll
+        for (int k = 0; k < NIT; ++k) {
+            const int i = tid + 256 * k;
+            const int r = i / PX_SW, c = i - r * PX_SW;
+            if (i < PX_SH * PX_SW) s_in[r * PX_SP + c] = v[k];
+        }
     }
     __syncthreads();
     // 2. vertical pass
