@@ -45,9 +45,10 @@ def _check_isa(verbose=False):
     if bad:
         for src, name, nfree, line in bad:
             sys.stderr.write("%s: kernel %s (next_free_vgpr %d): %s\n" % (src, name, nfree, line))
-        raise RuntimeError("64-bit shift by the last allocated VGPR: add IPX_VGPR_PAD(next_free_vgpr) to the kernels above")
+        raise RuntimeError("ISA check failed: a 64-bit shift by the last allocated VGPR needs IPX_VGPR_PAD_SAFE() in the kernel; "
+                           "unexpected private (scratch) memory means a register array left the registers")
     if verbose:
-        print("ISA check: no 64-bit shift by the last allocated VGPR")
+        print("ISA check: no 64-bit shift by the last allocated VGPR, no unexpected scratch memory")
 
 
 def build_lib(force=False, verbose=False):

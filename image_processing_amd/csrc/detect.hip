@@ -444,8 +444,9 @@ __global__ __launch_bounds__(256) void detect_kernel(DetectArgs a)
         uint4 v[NIT];
 #pragma unroll
         for (int k = 0; k < NIT; ++k) {
-            const int idx = tid + 256 * k, r = idx / (WIN_W / 16), q = idx - r * (WIN_W / 16);
-            if (idx < WIN_H * (WIN_W / 16)) v[k] = *reinterpret_cast<const uint4 *>(base + (size_t)r * W + 16 * q);
+            // (the spare lanes of the last round repeat the last item: an unconditional load keeps v[] in registers)
+            const int idx = min(tid + 256 * k, WIN_H * (WIN_W / 16) - 1), r = idx / (WIN_W / 16), q = idx - r * (WIN_W / 16);
+            v[k] = *reinterpret_cast<const uint4 *>(base + (size_t)r * W + 16 * q);
         }
 #pragma unroll
         for (int k = 0; k < NIT; ++k) {

@@ -410,9 +410,10 @@ __global__ __launch_bounds__(256) void pyr3_kernel(PyrArgs a)
 __host__ __device__ inline size_t r_stride(size_t P) { return (5 * P + 3) & ~(size_t)3; }
 
 constexpr int PX_TW = 64, PX_TH = 16, PX_SW = PX_TW + 2 * POLY_N, PX_SH = PX_TH + 2 * POLY_N, PX_SP = PX_SW + 1;
+constexpr int PX_IP = 80, PX_OX = 3;      // staged window: 80 columns from x0 - 8 (16-byte aligned rows); window column c is staged column c + 3
 __global__ __launch_bounds__(256) void polyexp_kernel(const float *I, int h, int w, int tiles_x, int tiles_y, int nf, PolyConst pc, float *R)
 {
-    __shared__ float s_in[PX_SH * PX_SP];
+    __shared__ __align__(16) float s_in[PX_SH * PX_IP];
     __shared__ float s_t[3][PX_TH][PX_SP];
     const int tid = threadIdx.x;
     const int per_frame = tiles_x * tiles_y, total = per_frame * nf, per_xcd = (total + 7) >> 3;
@@ -423,9 +424,27 @@ __global__ __launch_bounds__(256) void polyexp_kernel(const float *I, int h, int
     const int ty = rem / tiles_x, tx = rem - ty * tiles_x;
     const int x0 = tx * PX_TW, y0 = ty * PX_TH;
     const float *img = I + (size_t)f * h * w;
-    // 1. window: all of a thread's loads are issued before the first is stored (a rolled loop waits for every load
-    // before it issues the next: eight serial trips to memory per tile)
-    {
+    // 1. window.  All of a thread's loads are issued before the first is stored (a rolled loop waits for every load
+    // before it issues the next).  Tiles away from the left and right image borders take whole 16-byte groups (three
+    // loads per thread); the others clamp every column.
+    if (x0 >= 8 && x0 + PX_IP - 8 <= w && (w & 3) == 0) {
+        constexpr int NQ = PX_IP / 4, NIT = (PX_SH * NQ + 255) / 256;
+        float4 v[NIT];
+#pragma unroll
+        for (int k = 0; k < NIT; ++k) {
+            const int i = min(tid + 256 * k, PX_SH * NQ - 1);          // (the spare lanes of the last round repeat the last item)
+            const int r = i / NQ, q = i - r * NQ;
+            int y = y0 - POLY_N + r;
+            y = y < 0 ? 0 : (y > h - 1 ? h - 1 : y);
+            v[k] = *reinterpret_cast<const float4 *>(img + (unsigned)(y * w + x0 - 8 + 4 * q));
+        }
+#pragma unroll
+        for (int k = 0; k < NIT; ++k) {
+            const int i = tid + 256 * k;
+            const int r = i / NQ, q = i - r * NQ;
+            if (i < PX_SH * NQ) *reinterpret_cast<float4 *>(s_in + r * PX_IP + 4 * q) = v[k];
+        }
+    } else {
         constexpr int NIT = (PX_SH * PX_SW + 255) / 256;
         float v[NIT];
 #pragma unroll
@@ -441,18 +460,18 @@ __global__ __launch_bounds__(256) void polyexp_kernel(const float *I, int h, int
         for (int k = 0; k < NIT; ++k) {
             const int i = tid + 256 * k;
             const int r = i / PX_SW, c = i - r * PX_SW;
-            if (i < PX_SH * PX_SW) s_in[r * PX_SP + c] = v[k];
+            if (i < PX_SH * PX_SW) s_in[r * PX_IP + PX_OX + c] = v[k];
         }
     }
     __syncthreads();
     // 2. vertical pass
     for (int i = tid; i < PX_TH * PX_SW; i += 256) {
         const int r = i / PX_SW, c = i - r * PX_SW;
-        const float *S = s_in + (r + POLY_N) * PX_SP + c;
+        const float *S = s_in + (r + POLY_N) * PX_IP + PX_OX + c;
         float t0 = S[0] * pc.g[0], t1 = 0.f, t2 = 0.f;
 #pragma unroll
         for (int j = 1; j <= POLY_N; ++j) {
-            const float s0 = S[-j * PX_SP], s1 = S[j * PX_SP];
+            const float s0 = S[-j * PX_IP], s1 = S[j * PX_IP];
             const float p = s0 + s1;
             t0 = t0 + pc.g[j] * p;
             t1 = t1 + pc.xg[j] * (s1 - s0);

@@ -31,6 +31,11 @@ def main():
             e1.record()
             torch.cuda.synchronize()
             print("flow_metric(%d frames): %.3f ms" % (n, e0.elapsed_time(e1)), flush=True)
+        eng.profile_enable(True)
+        eng.profile_reset()
+        eng.flow_metric(fr)
+        for k, v in sorted(eng.profile_read().items(), key=lambda kv: -kv[1]["ms"]):
+            print("  %-12s launches %3d  total %8.3f ms" % (k, v["launches"], v["ms"]))
         return
     raw, bright, dense = eng.detect_raw(fr, keep)
     eng.remove_bright_regions(bright, raw, H, W, out=raw)

@@ -70,6 +70,27 @@ def check_asm(asm_text):
     return bad
 
 
+# Kernels that may use private (scratch) memory: everything else must keep its arrays in registers.  A register
+# array that the compiler cannot keep there (e.g. one assigned under a condition inside an unrolled loop) moves to
+# scratch silently and costs tens of per cent (polyexp_kernel in round 2: +31 %).
+SCRATCH_ALLOWED = ("persistent_kernel",)
+PRIVATE = re.compile(r"\s*\.amdhsa_private_segment_fixed_size\s+(\d+)")
+
+
+def check_scratch(asm_text):
+    """[(kernel, bytes)] for kernels with a private segment that are not in SCRATCH_ALLOWED."""
+    bad, kname = [], None
+    for line in asm_text.splitlines():
+        m = re.match(r"\s*\.amdhsa_kernel\s+(\S+)", line)
+        if m:
+            kname = m.group(1)
+            continue
+        m = PRIVATE.match(line)
+        if m and int(m.group(1)) > 0 and kname and not any(a in kname for a in SCRATCH_ALLOWED):
+            bad.append((kname, int(m.group(1))))
+    return bad
+
+
 def compile_to_asm(src, flags, hipcc="/opt/rocm/bin/hipcc"):
     with tempfile.TemporaryDirectory() as td:
         out = os.path.join(td, "k.s")
@@ -85,7 +106,9 @@ def check_library():
     flags = [f for f in b.FLAGS if f not in ("-fPIC",)]
     bad = []
     for s in b.SOURCES:
-        bad += [(s,) + x for x in check_asm(compile_to_asm(os.path.join(b.CSRC, s), flags, b._hipcc()))]   # the build's compiler
+        asm = compile_to_asm(os.path.join(b.CSRC, s), flags, b._hipcc())                                  # the build's compiler
+        bad += [(s,) + x for x in check_asm(asm)]
+        bad += [(s, name, 0, "uses %d bytes of private (scratch) memory per lane" % nbytes) for name, nbytes in check_scratch(asm)]
     return bad
 
 
@@ -93,5 +116,5 @@ if __name__ == "__main__":
     bad = check_library()
     for src, name, nfree, line in bad:
         print("%s: kernel %s (next_free_vgpr %d): %s" % (src, name, nfree, line))
-    print("%d offending shift(s)" % len(bad))
+    print("%d offending kernel(s)" % len(bad))
     sys.exit(1 if bad else 0)
