@@ -411,10 +411,17 @@ __host__ __device__ inline size_t r_stride(size_t P) { return (5 * P + 3) & ~(si
 
 constexpr int PX_TW = 64, PX_TH = 16, PX_SW = PX_TW + 2 * POLY_N, PX_SH = PX_TH + 2 * POLY_N, PX_SP = PX_SW + 1;
 constexpr int PX_IP = 80, PX_OX = 3;      // staged window: 80 columns from x0 - 8 (16-byte aligned rows); window column c is staged column c + 3
-__global__ __launch_bounds__(256) void polyexp_kernel(const float *I, int h, int w, int tiles_x, int tiles_y, int nf, PolyConst pc, float *R)
+// FUSED: level 0 of the usual pyramid (the frame itself under a 3x3 Gaussian, pyr3_kernel<0>) is evaluated while the
+// window is staged, straight from the uint8 frame, instead of being written to HBM by one kernel and read back by
+// this one: row pass p*k1 + (left + right)*k2 of the 28 source rows the window touches (reflect-101 at the image
+// borders, as the blur has them) into the LDS the vertical pass uses later, then the column pass
+// k1*mid + k2*(below + above) at the window's (replicated) rows -- the operations and their order are pyr3_kernel's.
+struct PxSrc { const uint8_t *frames, *extra; int first; float k1, k2; };
+template <bool FUSED>
+__global__ __launch_bounds__(256) void polyexp_kernel(const float *I, int h, int w, int tiles_x, int tiles_y, int nf, PolyConst pc, float *R, PxSrc src)
 {
     __shared__ __align__(16) float s_in[PX_SH * PX_IP];
-    __shared__ float s_t[3][PX_TH][PX_SP];
+    __shared__ __align__(16) float s_t[3][PX_TH][PX_SP];
     const int tid = threadIdx.x;
     const int per_frame = tiles_x * tiles_y, total = per_frame * nf, per_xcd = (total + 7) >> 3;
     const int k = (int)(blockIdx.x >> 3);
@@ -427,7 +434,69 @@ __global__ __launch_bounds__(256) void polyexp_kernel(const float *I, int h, int
     // 1. window.  All of a thread's loads are issued before the first is stored (a rolled loop waits for every load
     // before it issues the next).  Tiles away from the left and right image borders take whole 16-byte groups (three
     // loads per thread); the others clamp every column.
-    if (x0 >= 8 && x0 + PX_IP - 8 <= w && (w & 3) == 0) {
+    if (FUSED) {
+        constexpr int ER = PX_SH + 2, NQ = PX_IP / 4;          // source rows y0 - 6 .. y0 + 21, reflected: row-pass row e
+        float *s_rp = &s_t[0][0][0];                            // [ER][PX_IP], free until the vertical pass
+        static_assert(ER * PX_IP <= 3 * PX_TH * PX_SP, "row-pass rows must fit into s_t");
+        const int fi = src.first + f;
+        const uint8_t *frame = fi < 0 ? src.extra : src.frames + (size_t)fi * h * w;
+        const float k1 = src.k1, k2 = src.k2;
+        if (x0 >= 8 && x0 + PX_IP - 8 <= w) {                   // (w is a multiple of 4 on this path)
+            constexpr int NIT = (ER * NQ + 255) / 256;
+            uint32_t mid[NIT]; int lft[NIT], rgt[NIT];
+#pragma unroll
+            for (int k = 0; k < NIT; ++k) {
+                const int i = min(tid + 256 * k, ER * NQ - 1);
+                const int e = i / NQ, q = i - e * NQ;
+                const int x = x0 - 8 + 4 * q;
+                const uint8_t *row = frame + (size_t)reflect101(y0 - POLY_N - 1 + e, h) * w;
+                mid[k] = *reinterpret_cast<const uint32_t *>(row + x);
+                lft[k] = row[x - 1];                            // x0 >= 64 here
+                rgt[k] = row[x + 4 < w ? x + 4 : w - 2];        // reflect-101: column w is column w - 2
+            }
+#pragma unroll
+            for (int k = 0; k < NIT; ++k) {
+                const int i = tid + 256 * k;
+                const int e = i / NQ, q = i - e * NQ;
+                float pp[6];
+                pp[0] = (float)lft[k];
+                pp[1] = (float)(mid[k] & 0xff); pp[2] = (float)((mid[k] >> 8) & 0xff);
+                pp[3] = (float)((mid[k] >> 16) & 0xff); pp[4] = (float)(mid[k] >> 24);
+                pp[5] = (float)rgt[k];
+                float o[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) { float v = pp[c + 1] * k1; v += (pp[c] + pp[c + 2]) * k2; o[c] = v; }
+                if (i < ER * NQ) *reinterpret_cast<float4 *>(s_rp + e * PX_IP + 4 * q) = make_float4(o[0], o[1], o[2], o[3]);
+            }
+        } else {
+            for (int i = tid; i < ER * PX_SW; i += 256) {
+                const int e = i / PX_SW, c = i - e * PX_SW;
+                int x = x0 - POLY_N + c;
+                x = x < 0 ? 0 : (x > w - 1 ? w - 1 : x);
+                const uint8_t *row = frame + (size_t)reflect101(y0 - POLY_N - 1 + e, h) * w;
+                float v = (float)row[x] * k1;
+                v += ((float)row[reflect101(x - 1, w)] + (float)row[reflect101(x + 1, w)]) * k2;
+                s_rp[e * PX_IP + PX_OX + c] = v;
+            }
+        }
+        __syncthreads();
+        // column pass at the window's rows (replicated beyond the image): window row r <-> image row yc, row-pass rows
+        // e = yc - (y0 - 6) and its two neighbours
+        for (int i = tid; i < PX_SH * NQ; i += 256) {
+            const int r = i / NQ, q = i - r * NQ;
+            int yc = y0 - POLY_N + r;
+            yc = yc < 0 ? 0 : (yc > h - 1 ? h - 1 : yc);
+            const float *mrow = s_rp + (yc - y0 + POLY_N + 1) * PX_IP + 4 * q;
+            const float4 up = *reinterpret_cast<const float4 *>(mrow - PX_IP), md = *reinterpret_cast<const float4 *>(mrow),
+                         dn = *reinterpret_cast<const float4 *>(mrow + PX_IP);
+            float4 o;
+            o.x = k1 * md.x; o.x += k2 * (dn.x + up.x);
+            o.y = k1 * md.y; o.y += k2 * (dn.y + up.y);
+            o.z = k1 * md.z; o.z += k2 * (dn.z + up.z);
+            o.w = k1 * md.w; o.w += k2 * (dn.w + up.w);
+            *reinterpret_cast<float4 *>(s_in + r * PX_IP + 4 * q) = o;
+        }
+    } else if (x0 >= 8 && x0 + PX_IP - 8 <= w && (w & 3) == 0) {
         constexpr int NQ = PX_IP / 4, NIT = (PX_SH * NQ + 255) / 256;
         float4 v[NIT];
 #pragma unroll
@@ -1230,6 +1299,16 @@ int launch_level_expansion(ipx_ctx *ctx, const LevelGeom &g, const uint8_t *fram
     a.tiles_x = (g.lw + g.tox - 1) / g.tox; a.tiles_y = (g.lh + g.toy - 1) / g.toy; a.nf = nf;
     const dim3 grid(8 * ((a.tiles_x * a.tiles_y * nf + 7) / 8)), block(256);
     const double pyr_bytes = (double)nf * ((double)pl->H * pl->W + 4.0 * g.lh * g.lw);
+    // level 0 of the usual pyramid is not made at all: polyexp_kernel<true> evaluates it from the frames
+    const bool fused = g.ksize == 3 && g.mode == 0 && (pl->W & 3) == 0 && (pl->H & 3) == 0;
+    if (fused) {
+        PxSrc src = {frames, extra, first, g.kern[1], g.kern[2]};
+        const int ptx = (g.lw + PX_TW - 1) / PX_TW, pty = (g.lh + PX_TH - 1) / PX_TH;
+        IPX_LAUNCH(ctx, KID_POLYEXP, 21.0 * nf * g.lh * g.lw, polyexp_kernel<true>, dim3(8 * ((ptx * pty * nf + 7) / 8)), block, (const float *)nullptr,
+                   g.lh, g.lw, ptx, pty, nf, pl->pc, R, src);
+        IPX_LAUNCH_CHECK();
+        return IPX_OK;
+    }
     if (ctx->prof.on) ipx_prof_begin(ctx, KID_PYR, pyr_bytes);
     if (g.ksize == 3 && g.mode <= 1 && (pl->W & 3) == 0 && (pl->H & 3) == 0) {
         const dim3 g3((pl->W / 4 + 63) / 64, (pl->H / 4 + 3) / 4, nf);
@@ -1246,7 +1325,8 @@ int launch_level_expansion(ipx_ctx *ctx, const LevelGeom &g, const uint8_t *fram
     }
     if (ctx->prof.on) ipx_prof_end(ctx);
     const int ptx = (g.lw + PX_TW - 1) / PX_TW, pty = (g.lh + PX_TH - 1) / PX_TH;
-    IPX_LAUNCH(ctx, KID_POLYEXP, 24.0 * nf * g.lh * g.lw, polyexp_kernel, dim3(8 * ((ptx * pty * nf + 7) / 8)), block, I, g.lh, g.lw, ptx, pty, nf, pl->pc, R);
+    IPX_LAUNCH(ctx, KID_POLYEXP, 24.0 * nf * g.lh * g.lw, polyexp_kernel<false>, dim3(8 * ((ptx * pty * nf + 7) / 8)), block, I, g.lh, g.lw, ptx, pty, nf, pl->pc, R,
+               PxSrc{nullptr, nullptr, 0, 0.f, 0.f});
     IPX_LAUNCH_CHECK();
     return IPX_OK;
 }

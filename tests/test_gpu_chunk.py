@@ -61,6 +61,29 @@ def test_farneback_pair_field(eng, shape, shift):
     assert abs(mgot - mref) <= FLOW_RTOL * max(mref, 1e-30)
 
 
+# Sizes with H and W multiples of 4: level 0 of the pyramid is then evaluated inside polyexp_kernel<true> (no level-0
+# image in HBM).  One tile in each direction (every tile touches a border), tiles whose window leaves the image on
+# one side only, interior tiles with 16-byte loads, a width that ends exactly at a tile edge (reflect-101 of column W),
+# heights below one tile and below the blur's reflection distance.
+@pytest.mark.parametrize("shape,shift", [((4, 4), 0.5), ((8, 36), 1.0), ((16, 64), 1.0), ((36, 72), 2.0), ((64, 128), 1.5),
+                                         ((20, 200), 2.0), ((100, 136), 3.0), ((52, 264), 0.7), ((132, 392), 5.0)])
+def test_farneback_pair_field_fused_level0(eng, shape, shift):
+    from oracle import cref
+    h, w = shape
+    for seed, noise in ((h * w, True), (h + w, False)):
+        if noise:                                      # white noise: every bit of the blur and the expansion matters
+            rng = np.random.default_rng(seed)
+            a = rng.integers(0, 256, (h, w)).astype(np.uint8); b = rng.integers(0, 256, (h, w)).astype(np.uint8)
+        else:
+            a, b = _moving_pair(seed, h, w, shift)
+        ref = cref.farneback(a.astype(np.float32), b.astype(np.float32))
+        got = eng.farneback_pair(eng.to_device(a.astype(np.float32)), eng.to_device(b.astype(np.float32))).cpu().numpy()
+        assert got.shape == ref.shape and np.isfinite(got).all()
+        err = np.abs(got.astype(np.float64) - ref.astype(np.float64))
+        scale = max(1.0, float(np.abs(ref).max()))
+        assert err.max() <= 1e-12 * scale, "%dx%d noise=%s: max |dflow| = %g (flow scale %g)" % (w, h, noise, err.max(), scale)
+
+
 def test_farneback_rejects_non_u8_images(eng):
     from image_processing_amd._ipx import IpxError
     a = np.full((40, 40), 10.5, np.float32)
