@@ -601,6 +601,23 @@ def _generate_plots(frames, *args, **kwargs):
         plot_heatmap(heatmap, *chunk, **out)
 
 
+def _finish_figure(show_plots, save_plots, output_folder, file_name, tight_first=False):
+    """Common tail of the plot functions: show and / or save the current figure as ``file_name`` (300 dpi), then close it.
+    The reference lays the figure out tightly before saving; its combined overview does so before showing as well."""
+    if tight_first:
+        plt.tight_layout()
+    if show_plots and not tight_first:
+        plt.show()
+    if save_plots:
+        if not tight_first:
+            plt.tight_layout()
+        os.makedirs(output_folder, exist_ok=True)
+        plt.savefig(os.path.join(output_folder, file_name), dpi=300)
+    if show_plots and tight_first:
+        plt.show()
+    plt.close()
+
+
 def _blend(base, overlay):
     """cv2.addWeighted(base, 0.8, overlay, 1.0, 0) for uint8 images."""
     return np.clip(np.rint(base.astype(np.float64) * 0.8 + overlay.astype(np.float64)), 0, 255).astype(np.uint8)
@@ -645,14 +662,7 @@ def visualise_damaged_pixels(frame, frame_index, *args, **kwargs):
     plt.legend(handles=[mpatches.Patch(color="orange", label="Damaged Pixels"),
                         mpatches.Patch(color="royalblue", label="Bright Background Areas")],
                loc="upper left", fontsize="small", frameon=True)
-    if show_plots:
-        plt.show()
-    if save_plots:
-        plt.tight_layout()
-        os.makedirs(output_folder, exist_ok=True)
-        plt.savefig(os.path.join(output_folder,
-                                 f"visualise_damaged_pixels_frame_{chunk_index=}_{frame_index=}.png"), dpi=300)
-    plt.close()
+    _finish_figure(show_plots, save_plots, output_folder, f"visualise_damaged_pixels_frame_{chunk_index=}_{frame_index=}.png")
 
 
 def plot_heatmap(heatmap, chunk_index=None, title="Damaged Pixel Heatmap", show_plots=True, save_plots=False,
@@ -665,13 +675,7 @@ def plot_heatmap(heatmap, chunk_index=None, title="Damaged Pixel Heatmap", show_
     plt.imshow(heatmap, cmap="viridis", interpolation="nearest")
     plt.colorbar(label="Percentage of frames (%)")
     plt.title(f"{title} ({chunk_index = })")
-    if show_plots:
-        plt.show()
-    if save_plots:
-        plt.tight_layout()
-        os.makedirs(output_folder, exist_ok=True)
-        plt.savefig(os.path.join(output_folder, f"{title.lower().replace(' ', '_')}_{chunk_index=}.png"), dpi=300)
-    plt.close()
+    _finish_figure(show_plots, save_plots, output_folder, f"{title.lower().replace(' ', '_')}_{chunk_index=}.png")
 
 
 def plot_damaged_pixels(damaged_pixel_counts, chunk_index=None, show_plots=True, save_plots=False,
@@ -686,13 +690,7 @@ def plot_damaged_pixels(damaged_pixel_counts, chunk_index=None, show_plots=True,
     plt.ylabel("Number of Damaged Pixels")
     plt.title(f"Damaged Pixels Detected Over Time ({chunk_index = })")
     plt.legend()
-    if show_plots:
-        plt.show()
-    if save_plots:
-        plt.tight_layout()
-        os.makedirs(output_folder, exist_ok=True)
-        plt.savefig(os.path.join(output_folder, f"plot_damged_pixels_{chunk_index=}.png"), dpi=300)
-    plt.close()
+    _finish_figure(show_plots, save_plots, output_folder, f"plot_damged_pixels_{chunk_index=}.png")
 
 
 def chunked_nanmean(array, step):
@@ -727,13 +725,7 @@ def plot_all_chunks(all_counts, all_clusters, all_sizes, all_brightness, times, 
     if times is not None:
         for ax in axes:
             ax.set_xlim([0, len(times)])
-    plt.tight_layout()
-    if save_plots:
-        os.makedirs(output_folder, exist_ok=True)
-        plt.savefig(os.path.join(output_folder, "combined_chunks_overview.png"), dpi=300)
-    if show_plots:
-        plt.show()
-    plt.close()
+    _finish_figure(show_plots, save_plots, output_folder, "combined_chunks_overview.png", tight_first=True)
 
 
 # ---------------------------------------------------------------------------------------------
