@@ -237,7 +237,9 @@ int ipx_detect_chunk(ipx_ctx *ctx, const uint8_t *frames, int n, int H, int W,
  * frames.  transport: IPX_GROUP_RCCL = ncclAllGather / ncclAllReduce on an ncclCommInitAll communicator (librccl
  * is loaded at run time; devices must be distinct; a group of one still runs its collectives), IPX_GROUP_PEER =
  * hipMemcpyPeerAsync between the ranks' buffers (a device may be listed more than once), IPX_GROUP_AUTO = RCCL
- * for two or more distinct devices when librccl loads, else peer copies.  devices == NULL means 0 .. ndev-1. */
+ * for two or more distinct devices when librccl loads, else peer copies.  devices == NULL means 0 .. ndev-1.
+ * One ipx_group_detect_chunk at a time per group (the call is synchronous; use one group per calling thread).  When a
+ * rank fails, all ranks stop at their next meeting point and the call returns that rank's status and message. */
 typedef struct ipx_group ipx_group;
 #define IPX_GROUP_AUTO 0
 #define IPX_GROUP_PEER 1
