@@ -40,6 +40,16 @@ if not os.path.exists(LIB_PATH):
         "%s is missing: build it with `python -m image_processing_amd.build` (hipcc, gfx950). "
         "image_processing_amd has no CPU fallback." % LIB_PATH)
 
+# One HIP runtime per process.  libipx.so names libamdhip64 by soname; torch ships its own copy and loads it by path.
+# If libipx.so came first it would bring in /opt/rocm's copy, torch would add its own, and the second runtime to
+# initialise finds no device ("no ROCm-capable device is detected").  With torch imported first the soname resolves
+# to the copy already in the process.  (A caller without torch, e.g. tests/c_abi/group_example.c, simply uses
+# /opt/rocm's runtime.)
+try:
+    import torch  # noqa: F401
+except ImportError:                                      # pragma: no cover - the Python host needs torch anyway
+    pass
+
 lib = C.CDLL(LIB_PATH)
 
 _p = C.c_void_p
