@@ -125,6 +125,16 @@ _Zgood:
 \t\t.amdhsa_next_free_vgpr 17
 """
     assert [b[0] for b in mod.check_asm(sample)] == ["_Zbad"]
+    # the same scan refuses kernels whose register arrays ended up in private (scratch) memory
+    spills = """
+	.amdhsa_kernel _Zspills
+		.amdhsa_private_segment_fixed_size 64
+	.amdhsa_kernel _Zclean
+		.amdhsa_private_segment_fixed_size 0
+	.amdhsa_kernel _ZN12_GLOBAL__N_117persistent_kernelILi24ELb1EEEvPKmPKhimiiPm
+		.amdhsa_private_segment_fixed_size 24
+"""
+    assert mod.check_scratch(spills) == [("_Zspills", 64)]
     assert mod.check_library() == []
 
 
