@@ -30,6 +30,17 @@
 #include <string.h>
 #include <stdlib.h>
 #include <vector>
+#include <type_traits>
+
+// Ablation builds (tools/fi_ablate.py, timing only, results are garbage): bit 0 = the consumer waves do no work,
+// bit 1 = the second expansion is sampled from the pair's first frame (its lines are L1 hits), bit 2 = the
+// producers replace the matrix arithmetic by plain sums of what they loaded.
+#ifndef IPX_FI_C_BPERMUTE
+#define IPX_FI_C_BPERMUTE 0      // 1: phase C exchanges its pair and quad sums with ds_bpermute (the round-2 form)
+#endif
+#ifndef IPX_FI_ABLATE
+#define IPX_FI_ABLATE 0
+#endif
 
 namespace {
 
@@ -614,6 +625,9 @@ __device__ __forceinline__ void um_load(__amdgpu_buffer_rsrc_t rR, unsigned FS, 
     const unsigned o1 = (unsigned)(y * w + x);
     const unsigned dead = 0xfffffff0u;
     int x1, y1; float fx, fy;
+#if IPX_FI_ABLATE & 2
+    FS = 0;
+#endif
     const bool inb = um_position(d, x, y, h, w, x1, y1, fx, fy) && live;
     const ipx_u32x4 c03 = __builtin_amdgcn_raw_buffer_load_b128(rR, live ? o1 * 16u : dead, 0, 0);
     in.r0[4] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rR, live ? o1 * 4u : dead, P16, 0));
@@ -636,6 +650,10 @@ __device__ __forceinline__ void um_load(__amdgpu_buffer_rsrc_t rR, unsigned FS, 
 
 __device__ __forceinline__ void um_finish(const UmIn &in, float2 d, int x, int y, int h, int w, float (&m)[5])
 {
+#if IPX_FI_ABLATE & 4
+    for (int c = 0; c < 5; ++c) m[c] = (in.r0[c] + in.q[c][0]) + (in.q[c][1] + in.q[c][2]) + (in.q[c][3] + d.x);
+    return;
+#endif
     const float dx = d.x, dy = d.y;
     int x1, y1; float fx, fy;
     const bool inb = um_position(d, x, y, h, w, x1, y1, fx, fy);
@@ -734,6 +752,7 @@ struct FiVec {                  // a flow vector in flight: IN 0 uses p00 only
     float b1;
 };
 
+#if IPX_FI_C_BPERMUTE
 // the f64 value `v` of the lane whose byte address (4 * lane) is `addr`
 __device__ __forceinline__ double fi_lane_f64(double v, int addr)
 {
@@ -741,6 +760,7 @@ __device__ __forceinline__ double fi_lane_f64(double v, int addr)
     const int hi = __builtin_amdgcn_ds_bpermute(addr, __double2hiint(v));
     return __hiloint2double(hi, lo);
 }
+#endif
 
 // workgroup barrier that orders LDS traffic only: global loads stay in flight across it
 __device__ __forceinline__ void fi_barrier()
@@ -767,7 +787,7 @@ __global__ __launch_bounds__(FI_THREADS, 4) void flow_iter_kernel(const FiArgs a
     const int h = a.h, w = a.w, seg_rows = a.seg_rows, strips = a.strips, np = a.np, ppx = a.ppx;
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    if (a.prio) __builtin_amdgcn_s_setprio(3);
+    if (a.prio == 1 || (a.prio == 2 && wave < 4) || (a.prio == 3 && wave >= 4)) __builtin_amdgcn_s_setprio(3);
     // Workgroups go round-robin over the 8 XCDs (id % 8) and every XCD has its own L2.  XCD x gets the
     // pairs [x*ppx, (x+1)*ppx), and its resident workgroups are the same strip/segment of consecutive
     // pairs, then the neighbouring strips: the expansion of frame p+1 (sampled by pair p, read in place by
@@ -897,8 +917,10 @@ __global__ __launch_bounds__(FI_THREADS, 4) void flow_iter_kernel(const FiArgs a
                 if (c < nbch) vs[c] += (double)colb[i * FI_MROW + c * FI_MC];
         }
     }
+#if IPX_FI_C_BPERMUTE
     const int lane_a1 = ((tid + 1) & 63) << 2, lane_a3 = ((tid + 3) & 63) << 2, lane_a5 = ((tid + 5) & 63) << 2,
               lane_a7 = ((tid + 7) & 63) << 2;             // phase C: the lanes 1, 3, 5, 7 to the right (ds_bpermute addresses)
+#endif
     int slot_in = 15;                                    // slot of row yb+7 for yb = ys
     int slot_out = 1;                                    // slot of row ys-7, the first row to leave the window
     double msum = 0.0;
@@ -927,6 +949,27 @@ __global__ __launch_bounds__(FI_THREADS, 4) void flow_iter_kernel(const FiArgs a
             for (int c = 0; c < 3; ++c)
                 if (c < nbch) vob[c * (FI_G * FI_MC) + r * FI_MC] = vs[c];
         }
+    };
+    // Every step but the first: the same update without a branch, all of the step's ring reads issued before the
+    // first is used (rolled up row by row the wave would pay the LDS round trip four times per step).
+    auto phase_b_fast = [&](auto nch_tag) {
+        constexpr int NCH = decltype(nch_tag)::value;
+        float din[FI_G][NCH], dout[FI_G][NCH];
+#pragma unroll
+        for (int r = 0; r < FI_G; ++r) {
+            const float *pin = colb + slot_in * FI_MROW, *pout = colb + slot_out * FI_MROW;
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) { din[r][c] = pin[c * FI_MC]; dout[r][c] = pout[c * FI_MC]; }
+            slot_out = slot_out + 1 == FI_RING ? 0 : slot_out + 1;
+            slot_in = slot_in + 1 == FI_RING ? 0 : slot_in + 1;
+        }
+#pragma unroll
+        for (int r = 0; r < FI_G; ++r)
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) {
+                vs[c] += (double)(din[r][c] - dout[r][c]);
+                vob[c * (FI_G * FI_MC) + r * FI_MC] = vs[c];
+            }
     };
     // the four consumer waves meet here between B and C; the producers are not held up by it
     auto consumers_sync = [&]() {
@@ -997,7 +1040,13 @@ __global__ __launch_bounds__(FI_THREADS, 4) void flow_iter_kernel(const FiArgs a
     } else {
 #pragma unroll 1
         for (int yb = ys; yb < ye; yb += FI_G) {
-            phase_b(yb == ys);
+#if IPX_FI_ABLATE & 1
+            fi_barrier();
+            continue;
+#endif
+            if (yb == ys) phase_b(true);
+            else if (bhalf == 0) phase_b_fast(std::integral_constant<int, 3>());
+            else phase_b_fast(std::integral_constant<int, 2>());
             FI_STAMP(1);
             consumers_sync();
             FI_STAMP(2);
@@ -1013,6 +1062,7 @@ __global__ __launch_bounds__(FI_THREADS, 4) void flow_iter_kernel(const FiArgs a
                 //   window(2l) = (p[l] + Q) + v[2l+14],  window(2l+1) = (v[2l+1] + Q) + p[l+7]
                 // All 64 lanes take part (lanes 57-63 only as sources; what they compute themselves is dropped).
                 double acc[2][5];
+#if IPX_FI_C_BPERMUTE
 #pragma unroll
                 for (int ch = 0; ch < 5; ++ch) {
                     const double *ve = s_v + ch * (FI_G * FI_MC) + r * FI_MC + l;
@@ -1023,6 +1073,45 @@ __global__ __launch_bounds__(FI_THREADS, 4) void flow_iter_kernel(const FiArgs a
                     acc[0][ch] = (pr + Q) + v14;
                     acc[1][ch] = (v1 + Q) + fi_lane_f64(pr, lane_a7);
                 }
+#else
+                // The lanes hand each other p and q through the row's own LDS words, which only this wave touches
+                // and whose values are in registers by then: p[l] replaces v[2l], q[l] replaces v[2l+1].  A wave's
+                // LDS operations execute in order, so a later read sees an earlier write of another lane; the empty
+                // asm statements keep the compiler from moving a read of one word across the write of another
+                // (to one thread they are unrelated).  8-byte reads and writes cost the LDS pipe 2 and 6 cycles, the
+                // two ds_bpermute of an f64 exchange 4 each: 28 instead of 46 cycles per channel.
+                double *vrow = s_v + r * FI_MC + l;
+                const int lq = min(l, FI_HALF - 6);                  // lanes 59-63 own no output: keep their reads inside the row
+                double v1[5], v14[5], pr[5], q[5];
+#pragma unroll
+                for (int ch = 0; ch < 5; ++ch) {
+                    const double *ve = vrow + ch * (FI_G * FI_MC);
+                    v1[ch] = ve[FI_HALF]; v14[ch] = ve[FI_M];
+                    pr[ch] = ve[0] + v1[ch];
+                }
+                asm volatile("" ::: "memory");
+#pragma unroll
+                for (int ch = 0; ch < 5; ++ch) vrow[ch * (FI_G * FI_MC)] = pr[ch];
+                asm volatile("" ::: "memory");
+                double p1[5], p7[5];
+#pragma unroll
+                for (int ch = 0; ch < 5; ++ch) {
+                    const double *ve = vrow + ch * (FI_G * FI_MC);
+                    p1[ch] = ve[1]; p7[ch] = ve[FI_M];
+                    q[ch] = pr[ch] + p1[ch];
+                }
+                asm volatile("" ::: "memory");
+#pragma unroll
+                for (int ch = 0; ch < 5; ++ch) vrow[ch * (FI_G * FI_MC) + FI_HALF] = q[ch];
+                asm volatile("" ::: "memory");
+#pragma unroll
+                for (int ch = 0; ch < 5; ++ch) {
+                    const double *vq = s_v + ch * (FI_G * FI_MC) + r * FI_MC + FI_HALF + lq;
+                    const double Q = (vq[1] + vq[3]) + vq[5];
+                    acc[0][ch] = (pr[ch] + Q) + v14[ch];
+                    acc[1][ch] = (v1[ch] + Q) + p7[ch];
+                }
+#endif
                 const double scale = 1.0 / (double)((2 * FI_M + 1) * (2 * FI_M + 1));
                 float2 o[2];
 #pragma unroll
@@ -1380,7 +1469,7 @@ int run_pairs(ipx_ctx *ctx, const uint8_t *frames, const uint8_t *extra, int fir
         a.h = g.lh; a.w = g.lw; a.seg_rows = f.seg_rows; a.strips = f.strips; a.nseg = f.nseg; a.np = np; a.ppx = f.ppx;
         a.sh = a.sw = 0; a.x_ofs = a.y_ofs = nullptr; a.x_a = a.y_b = nullptr;
         a.err = err; a.spin_limit = ctx->fi_spin_limit;
-        a.prio = getenv("IPX_FI_PRIO") != nullptr;
+        a.prio = getenv("IPX_FI_PRIO") ? atoi(getenv("IPX_FI_PRIO")) : 0;   // probe: 1 = all waves, 2 = consumers, 3 = producers at high priority
         FiProbe *probe = k == 0 ? fi_probe() : nullptr;
         const bool probe_alone = probe && getenv("IPX_FI_OVERLAP_ALONE") != nullptr;   // the burn without the iterations beside it
         if (probe) {
