@@ -34,7 +34,8 @@
 
 // Ablation builds (tools/fi_ablate.py, timing only, results are garbage): bit 0 = the consumer waves do no work,
 // bit 1 = the second expansion is sampled from the pair's first frame (its lines are L1 hits), bit 2 = the
-// producers replace the matrix arithmetic by plain sums of what they loaded.
+// producers replace the matrix arithmetic by plain sums of what they loaded, bit 3 = one of the four bilinear taps
+// is loaded (44 instead of 108 bytes per matrix pixel through L1).
 #ifndef IPX_FI_C_BPERMUTE
 #define IPX_FI_C_BPERMUTE 0      // 1: phase C exchanges its pair and quad sums with ds_bpermute (the round-2 form)
 #endif
@@ -636,11 +637,18 @@ __device__ __forceinline__ void um_load(__amdgpu_buffer_rsrc_t rR, unsigned FS, 
     const unsigned q1 = (unsigned)(y1 * w + x1);
     const unsigned qa = inb ? q1 * 16u : dead, qb = inb ? (q1 + (unsigned)w) * 16u : dead;
     const ipx_u32x4 s00 = __builtin_amdgcn_raw_buffer_load_b128(rR, qa, FS, 0);
+#if IPX_FI_ABLATE & 8
+    const ipx_u32x4 s01 = s00, s10 = s00, s11 = s00;
+    (void)qb;
+    const ipx_u32x2 e0 = __builtin_amdgcn_raw_buffer_load_b64(rR, inb ? q1 * 4u : dead, FS + P16, 0);
+    const ipx_u32x2 e1 = e0;
+#else
     const ipx_u32x4 s01 = __builtin_amdgcn_raw_buffer_load_b128(rR, inb ? qa + 16u : dead, FS, 0);
     const ipx_u32x4 s10 = __builtin_amdgcn_raw_buffer_load_b128(rR, qb, FS, 0);
     const ipx_u32x4 s11 = __builtin_amdgcn_raw_buffer_load_b128(rR, inb ? qb + 16u : dead, FS, 0);
     const ipx_u32x2 e0 = __builtin_amdgcn_raw_buffer_load_b64(rR, inb ? q1 * 4u : dead, FS + P16, 0);
     const ipx_u32x2 e1 = __builtin_amdgcn_raw_buffer_load_b64(rR, inb ? (q1 + (unsigned)w) * 4u : dead, FS + P16, 0);
+#endif
     in.q[0][0] = __uint_as_float(s00.x); in.q[0][1] = __uint_as_float(s01.x); in.q[0][2] = __uint_as_float(s10.x); in.q[0][3] = __uint_as_float(s11.x);
     in.q[1][0] = __uint_as_float(s00.y); in.q[1][1] = __uint_as_float(s01.y); in.q[1][2] = __uint_as_float(s10.y); in.q[1][3] = __uint_as_float(s11.y);
     in.q[2][0] = __uint_as_float(s00.z); in.q[2][1] = __uint_as_float(s01.z); in.q[2][2] = __uint_as_float(s10.z); in.q[2][3] = __uint_as_float(s11.z);
@@ -1123,9 +1131,14 @@ __global__ __launch_bounds__(FI_THREADS, 4) void flow_iter_kernel(const FiArgs a
                     o[j].y = (float)((g22 * h1 - g12 * h2) * idet);
                 }
                 const int x = l < FI_TW / 2 ? x0 + 2 * l : w;     // lanes 57-63 own no output
+                // both solves are finished before anything is stored: left to itself the compiler moves the second one
+                // behind the test of x + 1 < w, and the two division chains then run one after the other
+                asm volatile("" : "+v"(o[0].x), "+v"(o[0].y), "+v"(o[1].x), "+v"(o[1].y));
                 if (REDUCE) {
-                    if (x < w) msum += (double)sqrtf(o[0].x * o[0].x + o[0].y * o[0].y);      // cartToPolar magnitude in f32
-                    if (x + 1 < w) msum += (double)sqrtf(o[1].x * o[1].x + o[1].y * o[1].y);
+                    float m0 = sqrtf(o[0].x * o[0].x + o[0].y * o[0].y), m1 = sqrtf(o[1].x * o[1].x + o[1].y * o[1].y);   // cartToPolar magnitude in f32
+                    asm volatile("" : "+v"(m0), "+v"(m1));
+                    msum += (double)(x < w ? m0 : 0.f);           // (adding +0 changes nothing: the sum is never -0)
+                    msum += (double)(x + 1 < w ? m1 : 0.f);
                 } else {
                     float2 *dst = fout + (size_t)y * w + x;
                     if (x + 1 < w && ((w & 1) == 0)) {
