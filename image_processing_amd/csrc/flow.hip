@@ -596,6 +596,8 @@ __global__ __launch_bounds__(256) void polyexp_kernel(const float *I, int h, int
 struct UmIn {
     float r0[5];        // R0 at the pixel
     float q[5][4];      // R1 at (x1,y1), (x1+1,y1), (x1,y1+1), (x1+1,y1+1); unset when the sample is out of bounds
+    float fx, fy;       // fractions of the sample position (um_position), kept from the loads to the arithmetic
+    bool inb;           // the sample is inside the second image
 };
 
 // bilinear sample position of pixel (x,y) displaced by d: integer corner, fractions, in-bounds test
@@ -617,37 +619,42 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t ipx_make_rsrc(const void *base
 
 // rR: the expansions of the pair's two frames (layout: polyexp_kernel), FS = bytes per frame, P16 = byte
 // offset of the fifth coefficient's plane.  16-byte loads fetch coefficients 0-3 of one pixel; the loads are
-// unconditional (no divergent control flow between issue and use): a sample position outside the image gets
-// an offset beyond the resource, for which the buffer load returns 0 without touching memory.
+// unconditional (no divergent control flow between issue and use).  A position that must not be read (a matrix
+// column or row that feeds nothing, a sample outside the image) is replaced by pixel index UM_DEAD ONCE, before
+// the offsets are derived from it: 16 * UM_DEAD lies beyond any resource (frames have at most 2^26 pixels, a
+// resource at most 40 * 2^26 bytes), so the 16-byte loads fetch nothing and return 0; the 4-byte plane's offset
+// 4 * UM_DEAD is beyond the resource for frames of up to 2^23 pixels and a harmless read inside it for larger
+// ones -- what such a load returns is never used.  The +16 / +1 row steps come after the select, so they fold
+// into the instructions' immediate offsets or cost one addition for both planes.
 typedef unsigned int ipx_u32x4 __attribute__((ext_vector_type(4)));
+constexpr unsigned UM_DEAD = 0x0f000000u;
 __device__ __forceinline__ void um_load(__amdgpu_buffer_rsrc_t rR, unsigned FS, unsigned P16, float2 d, int x, int y, int h, int w,
                                         UmIn &in, bool live = true)
 {
-    const unsigned o1 = (unsigned)(y * w + x);
-    const unsigned dead = 0xfffffff0u;
-    int x1, y1; float fx, fy;
+    const unsigned o1 = live ? (unsigned)(y * w + x) : UM_DEAD;
+    int x1, y1;
 #if IPX_FI_ABLATE & 2
     FS = 0;
 #endif
-    const bool inb = um_position(d, x, y, h, w, x1, y1, fx, fy) && live;
-    const ipx_u32x4 c03 = __builtin_amdgcn_raw_buffer_load_b128(rR, live ? o1 * 16u : dead, 0, 0);
-    in.r0[4] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rR, live ? o1 * 4u : dead, P16, 0));
+    in.inb = um_position(d, x, y, h, w, x1, y1, in.fx, in.fy);
+    const ipx_u32x4 c03 = __builtin_amdgcn_raw_buffer_load_b128(rR, o1 * 16u, 0, 0);
+    in.r0[4] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rR, o1 * 4u, P16, 0));
     in.r0[0] = __uint_as_float(c03.x); in.r0[1] = __uint_as_float(c03.y);
     in.r0[2] = __uint_as_float(c03.z); in.r0[3] = __uint_as_float(c03.w);
-    const unsigned q1 = (unsigned)(y1 * w + x1);
-    const unsigned qa = inb ? q1 * 16u : dead, qb = inb ? (q1 + (unsigned)w) * 16u : dead;
+    const unsigned q1 = in.inb && live ? (unsigned)(y1 * w + x1) : UM_DEAD;
+    const unsigned qa = q1 * 16u, qb = qa + 16u * (unsigned)w, qe = q1 * 4u;
     const ipx_u32x4 s00 = __builtin_amdgcn_raw_buffer_load_b128(rR, qa, FS, 0);
 #if IPX_FI_ABLATE & 8
     const ipx_u32x4 s01 = s00, s10 = s00, s11 = s00;
     (void)qb;
-    const ipx_u32x2 e0 = __builtin_amdgcn_raw_buffer_load_b64(rR, inb ? q1 * 4u : dead, FS + P16, 0);
+    const ipx_u32x2 e0 = __builtin_amdgcn_raw_buffer_load_b64(rR, qe, FS + P16, 0);
     const ipx_u32x2 e1 = e0;
 #else
-    const ipx_u32x4 s01 = __builtin_amdgcn_raw_buffer_load_b128(rR, inb ? qa + 16u : dead, FS, 0);
+    const ipx_u32x4 s01 = __builtin_amdgcn_raw_buffer_load_b128(rR, qa + 16u, FS, 0);
     const ipx_u32x4 s10 = __builtin_amdgcn_raw_buffer_load_b128(rR, qb, FS, 0);
-    const ipx_u32x4 s11 = __builtin_amdgcn_raw_buffer_load_b128(rR, inb ? qb + 16u : dead, FS, 0);
-    const ipx_u32x2 e0 = __builtin_amdgcn_raw_buffer_load_b64(rR, inb ? q1 * 4u : dead, FS + P16, 0);
-    const ipx_u32x2 e1 = __builtin_amdgcn_raw_buffer_load_b64(rR, inb ? (q1 + (unsigned)w) * 4u : dead, FS + P16, 0);
+    const ipx_u32x4 s11 = __builtin_amdgcn_raw_buffer_load_b128(rR, qb + 16u, FS, 0);
+    const ipx_u32x2 e0 = __builtin_amdgcn_raw_buffer_load_b64(rR, qe, FS + P16, 0);
+    const ipx_u32x2 e1 = __builtin_amdgcn_raw_buffer_load_b64(rR, qe + 4u * (unsigned)w, FS + P16, 0);
 #endif
     in.q[0][0] = __uint_as_float(s00.x); in.q[0][1] = __uint_as_float(s01.x); in.q[0][2] = __uint_as_float(s10.x); in.q[0][3] = __uint_as_float(s11.x);
     in.q[1][0] = __uint_as_float(s00.y); in.q[1][1] = __uint_as_float(s01.y); in.q[1][2] = __uint_as_float(s10.y); in.q[1][3] = __uint_as_float(s11.y);
@@ -663,8 +670,8 @@ __device__ __forceinline__ void um_finish(const UmIn &in, float2 d, int x, int y
     return;
 #endif
     const float dx = d.x, dy = d.y;
-    int x1, y1; float fx, fy;
-    const bool inb = um_position(d, x, y, h, w, x1, y1, fx, fy);
+    const float fx = in.fx, fy = in.fy;
+    const bool inb = in.inb;
     float r2, r3, r4, r5, r6;
     if (inb) {
         const float a00 = (1.f - fx) * (1.f - fy), a01 = fx * (1.f - fy), a10 = (1.f - fx) * fy, a11 = fx * fy;
@@ -1020,27 +1027,38 @@ __global__ __launch_bounds__(FI_THREADS, 4) void flow_iter_kernel(const FiArgs a
         // then waits for inside the loop are the worst case over both ways into it: without an empty queue
         // here every step would begin by waiting for all of the wave's loads, the row in flight included.
         __builtin_amdgcn_s_waitcnt(0x0F70);
+        // (rows of the loop are >= ys + 11: only the bottom clamp applies; the ring slots of the thread's two rows
+        // advance by 4 per step -- both spare the scalar unit a division and two selects per use)
+        auto clamp_hi = [&](int j) { return j > h - 1 ? h - 1 : j; };
+        auto ring_put = [&](int slot, const float (&m)[5]) {
+            float *dst = s_m + slot * FI_MROW + ac;
+#pragma unroll
+            for (int ch = 0; ch < 5; ++ch) dst[ch * FI_MC] = m[ch];
+        };
+        int slot0 = (FI_M + FI_G + prow + 8) % FI_RING, slot1 = (FI_M + FI_G + prow + 10) % FI_RING;
 #pragma unroll 1
         for (int yb = ys; yb < ye; yb += FI_G) {
             const bool more = yb + FI_G < ye;            // the next step needs matrix rows yb+11 .. yb+14 (in flight)
             const bool more2 = yb + 2 * FI_G < ye;       // and the one after it rows yb+15 .. yb+18 (issued here)
             const int j0 = yb + FI_M + FI_G + prow, j1 = j0 + 2;
             float m[5];
-            um_finish(in0, d0, ax, clamp_row(j0), h, w, m);
-            if (more) ring_store(j0, m);
+            um_finish(in0, d0, ax, clamp_hi(j0), h, w, m);
+            if (more) ring_put(slot0, m);
+            slot0 = slot0 + FI_G >= FI_RING ? slot0 + FI_G - FI_RING : slot0 + FI_G;
             FI_STAMP(0);
             d0 = vec_finish(dv0);
-            um_load(rR, FS, P16, d0, ax, clamp_row(j0 + FI_G), h, w, in0, more2 && col_used);
+            um_load(rR, FS, P16, d0, ax, clamp_hi(j0 + FI_G), h, w, in0, more2 && col_used);
             dv0 = vec_issue_t(tb0);
-            tb0 = row_tab(clamp_row(j0 + 3 * FI_G));
+            tb0 = row_tab(clamp_hi(j0 + 3 * FI_G));
             FI_STAMP(1);
-            um_finish(in1, d1, ax, clamp_row(j1), h, w, m);
-            if (more) ring_store(j1, m);
+            um_finish(in1, d1, ax, clamp_hi(j1), h, w, m);
+            if (more) ring_put(slot1, m);
+            slot1 = slot1 + FI_G >= FI_RING ? slot1 + FI_G - FI_RING : slot1 + FI_G;
             FI_STAMP(2);
             d1 = vec_finish(dv1);
-            um_load(rR, FS, P16, d1, ax, clamp_row(j1 + FI_G), h, w, in1, more2 && col_used);
+            um_load(rR, FS, P16, d1, ax, clamp_hi(j1 + FI_G), h, w, in1, more2 && col_used);
             dv1 = vec_issue_t(tb1);
-            tb1 = row_tab(clamp_row(j1 + 3 * FI_G));
+            tb1 = row_tab(clamp_hi(j1 + 3 * FI_G));
             FI_STAMP(3);
             fi_barrier();                                // ring rows of the next step written
             FI_STAMP(4);
@@ -1088,34 +1106,54 @@ __global__ __launch_bounds__(FI_THREADS, 4) void flow_iter_kernel(const FiArgs a
                 // asm statements keep the compiler from moving a read of one word across the write of another
                 // (to one thread they are unrelated).  8-byte reads and writes cost the LDS pipe 2 and 6 cycles, the
                 // two ds_bpermute of an f64 exchange 4 each: 28 instead of 46 cycles per channel.
+                // The reads are spelled out as ds_read_b64: the compiler would pair them into ds_read2_b64, which takes
+                // the LDS array 8 cycles for two values where two ds_read_b64 take 4 (MI355X_MICROARCH.md, LDS table).
+                // Byte offsets: channel 4096 (FI_G * FI_MC doubles), odd columns 512 (FI_HALF), 7 lanes on 56 (FI_M).
+                static_assert(FI_G * FI_MC * 8 == 4096 && FI_HALF * 8 == 512 && FI_M * 8 == 56, "offsets of the ds_read_b64 blocks");
                 double *vrow = s_v + r * FI_MC + l;
-                const int lq = min(l, FI_HALF - 6);                  // lanes 59-63 own no output: keep their reads inside the row
-                double v1[5], v14[5], pr[5], q[5];
+                const unsigned va = (unsigned)(uintptr_t)(__attribute__((address_space(3))) double *)vrow;
+                const unsigned vqa = va + 512u - 8u * (unsigned)(l - min(l, FI_HALF - 6));   // lanes 59-63 own no output: keep their reads inside the row
+                double v0[5], v1[5], v14[5], pr[5], q[5];
+                asm volatile("ds_read_b64 %0, %15\n\tds_read_b64 %1, %15 offset:512\n\tds_read_b64 %2, %15 offset:56\n\t"
+                             "ds_read_b64 %3, %15 offset:4096\n\tds_read_b64 %4, %15 offset:4608\n\tds_read_b64 %5, %15 offset:4152\n\t"
+                             "ds_read_b64 %6, %15 offset:8192\n\tds_read_b64 %7, %15 offset:8704\n\tds_read_b64 %8, %15 offset:8248\n\t"
+                             "ds_read_b64 %9, %15 offset:12288\n\tds_read_b64 %10, %15 offset:12800\n\tds_read_b64 %11, %15 offset:12344\n\t"
+                             "ds_read_b64 %12, %15 offset:16384\n\tds_read_b64 %13, %15 offset:16896\n\tds_read_b64 %14, %15 offset:16440\n\t"
+                             "s_waitcnt lgkmcnt(0)"
+                             : "=&v"(v0[0]), "=&v"(v1[0]), "=&v"(v14[0]), "=&v"(v0[1]), "=&v"(v1[1]), "=&v"(v14[1]), "=&v"(v0[2]), "=&v"(v1[2]),
+                               "=&v"(v14[2]), "=&v"(v0[3]), "=&v"(v1[3]), "=&v"(v14[3]), "=&v"(v0[4]), "=&v"(v1[4]), "=&v"(v14[4])
+                             : "v"(va) : "memory");
 #pragma unroll
-                for (int ch = 0; ch < 5; ++ch) {
-                    const double *ve = vrow + ch * (FI_G * FI_MC);
-                    v1[ch] = ve[FI_HALF]; v14[ch] = ve[FI_M];
-                    pr[ch] = ve[0] + v1[ch];
-                }
-                asm volatile("" ::: "memory");
+                for (int ch = 0; ch < 5; ++ch) pr[ch] = v0[ch] + v1[ch];
 #pragma unroll
                 for (int ch = 0; ch < 5; ++ch) vrow[ch * (FI_G * FI_MC)] = pr[ch];
-                asm volatile("" ::: "memory");
                 double p1[5], p7[5];
+                asm volatile("ds_read_b64 %0, %10 offset:8\n\tds_read_b64 %1, %10 offset:56\n\t"
+                             "ds_read_b64 %2, %10 offset:4104\n\tds_read_b64 %3, %10 offset:4152\n\t"
+                             "ds_read_b64 %4, %10 offset:8200\n\tds_read_b64 %5, %10 offset:8248\n\t"
+                             "ds_read_b64 %6, %10 offset:12296\n\tds_read_b64 %7, %10 offset:12344\n\t"
+                             "ds_read_b64 %8, %10 offset:16392\n\tds_read_b64 %9, %10 offset:16440\n\t"
+                             "s_waitcnt lgkmcnt(0)"
+                             : "=&v"(p1[0]), "=&v"(p7[0]), "=&v"(p1[1]), "=&v"(p7[1]), "=&v"(p1[2]), "=&v"(p7[2]), "=&v"(p1[3]), "=&v"(p7[3]),
+                               "=&v"(p1[4]), "=&v"(p7[4])
+                             : "v"(va) : "memory");
 #pragma unroll
-                for (int ch = 0; ch < 5; ++ch) {
-                    const double *ve = vrow + ch * (FI_G * FI_MC);
-                    p1[ch] = ve[1]; p7[ch] = ve[FI_M];
-                    q[ch] = pr[ch] + p1[ch];
-                }
-                asm volatile("" ::: "memory");
+                for (int ch = 0; ch < 5; ++ch) q[ch] = pr[ch] + p1[ch];
 #pragma unroll
                 for (int ch = 0; ch < 5; ++ch) vrow[ch * (FI_G * FI_MC) + FI_HALF] = q[ch];
-                asm volatile("" ::: "memory");
+                double q1[5], q3[5], q5[5];
+                asm volatile("ds_read_b64 %0, %15 offset:8\n\tds_read_b64 %1, %15 offset:24\n\tds_read_b64 %2, %15 offset:40\n\t"
+                             "ds_read_b64 %3, %15 offset:4104\n\tds_read_b64 %4, %15 offset:4120\n\tds_read_b64 %5, %15 offset:4136\n\t"
+                             "ds_read_b64 %6, %15 offset:8200\n\tds_read_b64 %7, %15 offset:8216\n\tds_read_b64 %8, %15 offset:8232\n\t"
+                             "ds_read_b64 %9, %15 offset:12296\n\tds_read_b64 %10, %15 offset:12312\n\tds_read_b64 %11, %15 offset:12328\n\t"
+                             "ds_read_b64 %12, %15 offset:16392\n\tds_read_b64 %13, %15 offset:16408\n\tds_read_b64 %14, %15 offset:16424\n\t"
+                             "s_waitcnt lgkmcnt(0)"
+                             : "=&v"(q1[0]), "=&v"(q3[0]), "=&v"(q5[0]), "=&v"(q1[1]), "=&v"(q3[1]), "=&v"(q5[1]), "=&v"(q1[2]), "=&v"(q3[2]),
+                               "=&v"(q5[2]), "=&v"(q1[3]), "=&v"(q3[3]), "=&v"(q5[3]), "=&v"(q1[4]), "=&v"(q3[4]), "=&v"(q5[4])
+                             : "v"(vqa) : "memory");
 #pragma unroll
                 for (int ch = 0; ch < 5; ++ch) {
-                    const double *vq = s_v + ch * (FI_G * FI_MC) + r * FI_MC + FI_HALF + lq;
-                    const double Q = (vq[1] + vq[3]) + vq[5];
+                    const double Q = (q1[ch] + q3[ch]) + q5[ch];
                     acc[0][ch] = (pr[ch] + Q) + v14[ch];
                     acc[1][ch] = (v1[ch] + Q) + p7[ch];
                 }
