@@ -327,8 +327,9 @@ __global__ __launch_bounds__(256) void pyr_level_kernel(PyrArgs a)
             vb += a.kt.k[R + j] * (t[R + 1 + j] + t[R + 1 - j]);
         }
     };
+    const int tox_sh = 31 - __builtin_clz(a.tox);
     for (int idx = tid; idx < a.tox * ndy; idx += 256) {
-        const int dyl = idx / a.tox, dxl = idx - dyl * a.tox;
+        const int dyl = idx >> tox_sh, dxl = idx - (dyl << tox_sh);   // tox is a power of two (build_plan)
         if (dxl >= ndx) continue;
         const int dx = dx0 + dxl, dy = dy0 + dyl;
         const int ra = a.ys2[2 * dy] - r_lo, rb = a.ys2[2 * dy + 1] - r_lo;
