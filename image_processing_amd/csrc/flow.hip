@@ -454,14 +454,18 @@ __global__ __launch_bounds__(256) void polyexp_kernel(const float *I, int h, int
         const int fi = src.first + f;
         const uint8_t *frame = fi < 0 ? src.extra : src.frames + (size_t)fi * h * w;
         const float k1 = src.k1, k2 = src.k2;
+        // (thread -> (row, quad) once: quad q = tid % 20 of rows e0, e0 + 12, e0 + 24; threads 240-255 idle here)
+        constexpr int QROWS = 240 / NQ;
+        static_assert(NQ * QROWS == 240, "20 quads x 12 rows per round");
+        const int sq = tid % NQ, se0 = tid / NQ;
+        const bool sact = tid < NQ * QROWS;
         if (x0 >= 8 && x0 + PX_IP - 8 <= w) {                   // (w is a multiple of 4 on this path)
-            constexpr int NIT = (ER * NQ + 255) / 256;
+            constexpr int NIT = (ER + QROWS - 1) / QROWS;
             uint32_t mid[NIT]; int lft[NIT], rgt[NIT];
+            const int x = x0 - 8 + 4 * sq;
 #pragma unroll
             for (int k = 0; k < NIT; ++k) {
-                const int i = min(tid + 256 * k, ER * NQ - 1);
-                const int e = i / NQ, q = i - e * NQ;
-                const int x = x0 - 8 + 4 * q;
+                const int e = min(se0 + QROWS * k, ER - 1);      // (spare lanes repeat the last row)
                 const uint8_t *row = frame + (size_t)reflect101(y0 - POLY_N - 1 + e, h) * w;
                 mid[k] = *reinterpret_cast<const uint32_t *>(row + x);
                 lft[k] = row[x - 1];                            // x0 >= 64 here
@@ -469,8 +473,7 @@ __global__ __launch_bounds__(256) void polyexp_kernel(const float *I, int h, int
             }
 #pragma unroll
             for (int k = 0; k < NIT; ++k) {
-                const int i = tid + 256 * k;
-                const int e = i / NQ, q = i - e * NQ;
+                const int e = se0 + QROWS * k;
                 float pp[6];
                 pp[0] = (float)lft[k];
                 pp[1] = (float)(mid[k] & 0xff); pp[2] = (float)((mid[k] >> 8) & 0xff);
@@ -479,7 +482,7 @@ __global__ __launch_bounds__(256) void polyexp_kernel(const float *I, int h, int
                 float o[4];
 #pragma unroll
                 for (int c = 0; c < 4; ++c) { float v = pp[c + 1] * k1; v += (pp[c] + pp[c + 2]) * k2; o[c] = v; }
-                if (i < ER * NQ) *reinterpret_cast<float4 *>(s_rp + e * PX_IP + 4 * q) = make_float4(o[0], o[1], o[2], o[3]);
+                if (sact && e < ER) *reinterpret_cast<float4 *>(s_rp + e * PX_IP + 4 * sq) = make_float4(o[0], o[1], o[2], o[3]);
             }
         } else {
             for (int i = tid; i < ER * PX_SW; i += 256) {
@@ -495,8 +498,8 @@ __global__ __launch_bounds__(256) void polyexp_kernel(const float *I, int h, int
         __syncthreads();
         // column pass at the window's rows (replicated beyond the image): window row r <-> image row yc, row-pass rows
         // e = yc - (y0 - 6) and its two neighbours
-        for (int i = tid; i < PX_SH * NQ; i += 256) {
-            const int r = i / NQ, q = i - r * NQ;
+        for (int r = se0; sact && r < PX_SH; r += QROWS) {
+            const int q = sq;
             int yc = y0 - POLY_N + r;
             yc = yc < 0 ? 0 : (yc > h - 1 ? h - 1 : yc);
             const float *mrow = s_rp + (yc - y0 + POLY_N + 1) * PX_IP + 4 * q;
@@ -744,23 +747,35 @@ __device__ __forceinline__ void um_finish(const UmIn &in, float2 d, int x, int y
 // the ring is large enough (rows yb-8 .. yb+14) that the producers never write a row B still reads.
 // 79,376 bytes of LDS: two workgroups per CU.  Only the horizontal halo (128/114) and 18 rows per segment
 // are computed twice.
-// Measured on MI355X (in-kernel stamps + PMC, 1080p, two workgroups per CU): a step takes ~5.5k cycles.  The
-// producers spend all of it blocked on the vector memory pipe (issue or data): the CU fetches ~25 KB of L1
-// misses per workgroup step, i.e. ~9 B/cycle/CU, which is what one CU gets from the fabric (~46 requests
-// outstanding at ~480 cycles each).  HBM itself is far from busy (halving the L2 misses with the XCD-aware
-// order changed nothing), and so are VALU (45 %) and LDS (46 %).  A level-0 launch runs at the rate of a
-// device-to-device copy (~4.9 TB/s algorithmic); the small levels (3 strips for 240 columns, short segments)
-// pull the average down.  What moved the time: fewer L1 line requests per pixel (float4 expansion planes:
-// 8 loads instead of 15), keeping requests queued at all times (row pipeline), taking B and the B->C hand-off
-// off the producers, and nothing in the producers' loop that waits for a load it does not need: the loop
-// must not begin with loads in flight that the compiler ordered differently from the loop's own (its wait
-// counts are the worst case over both entries), no loaded value may be copied at the loop's end, and tables
-// that are uniform per wave must be scalar loads (see row_tab).  What did not: replacing the barrier by
-// counters so that the producers run ahead (5.7k: the memory pipe, not the waiting, sets their pace), deeper
-// prefetch, 64-column strips, one output per thread in C, and 1024-thread workgroups whose two halves take
-// consecutive pairs in lockstep so that the shared expansion is fetched once per CU (the half that benefits
-// drops to 3.6k of producer work, but the coupled barrier costs more than that: 6.0k per step; with one
-// counter barrier per half the halves drift apart and the slower one sets the time).
+// Measured on MI355X (in-kernel stamps, PMC, ablation builds: tools/fi_stamps.py, tools/pmc_stage.sh,
+// tools/fi_ablate.py; 1080p, two workgroups per CU).  A step takes ~4.3k cycles (round 2 began at 5.5k).  No single
+// resource sets it: the vector ALUs are 77 % busy (~3.0 wave instructions per output pixel: producers 52 %, C 30 %,
+// B 18 %), the LDS 52 %, and three floors lie close together -- the ALU work alone (77 % of the time), the
+// producers alone (consumer waves idle: 75 %; they are then paced by the 108 bytes per matrix pixel that the
+// 16 loads pull through L1: loading one bilinear tap instead of four takes another 18 % off, replacing their
+// arithmetic only 4 %) and HBM (one tap, no consumers: 6.2 TB/s, the streaming rate of the device; 60 % of the
+// time).  Sampling the second expansion from the pair's first frame (its lines L1 hits) changes 5 %: the misses
+// are not what the kernel waits for.  The two wave roles are balanced to within 8 % (producers 3.7k busy cycles per
+// step, consumers 3.4k); the rest of a step is the skew of eight waves meeting at the barrier.
+// What moved the time in round 2 (5.5k -> 4.3k): phase C was the critical path -- its ds_bpermute exchanges (4 LDS
+// cycles per 32 bits moved) are now 8-byte reads and writes in place (see there), the reads spelled as ds_read_b64
+// because the compiler's ds_read2_b64 pairs take the LDS array twice as long; phase B without branches, all ring
+// reads of a step in flight at once; the producers with one dead-offset select per position instead of one per
+// load, the sample fractions kept from the loads to the arithmetic, running ring slots (-14 % of their vector
+// instructions).  Earlier: fewer L1 line requests per pixel (float4 expansion planes: 8 loads instead of 15),
+// keeping requests queued at all times (row pipeline), taking B and the B->C hand-off off the producers, and
+// nothing in the producers' loop that waits for a load it does not need: the loop must not begin with loads in
+// flight that the compiler ordered differently from the loop's own (its wait counts are the worst case over both
+// entries), no loaded value may be copied at the loop's end, and tables that are uniform per wave must be scalar
+// loads (see row_tab).
+// What did not: LDS counters in place of the step barrier (producers wait for B of the step before, consumers for
+// the producers' stores and for C of the step before, every counter read issued ahead of its use: +3 %, the
+// polls cost what the skew did); a second workgroup barrier in place of the B -> C counter (+2 %: the producers'
+// loads leave later); the in-bounds test of the sample as selects instead of a branch (+1.5 %); wave priorities
+// (consumers or producers raised: +-0); padding the rows of vertical sums so that B's 8-byte stores hit distinct
+// banks (the two-way conflicts are 15 % of the LDS cycles and cost nothing); deeper prefetch, 64-column strips,
+// one output per thread in C, and 1024-thread workgroups whose two halves take consecutive pairs in lockstep so
+// that the shared expansion is fetched once per CU (the coupled barrier costs more than the saved misses return).
 constexpr int FI_M = 7, FI_MC = 128, FI_G = 4, FI_TW = FI_MC - 2 * FI_M, FI_THREADS = 512;
 constexpr int FI_RING = 23, FI_MROW = 5 * FI_MC, FI_HALF = FI_MC / 2;
 constexpr size_t FI_LDS_BYTES = FI_RING * FI_MROW * sizeof(float) + 5 * FI_G * FI_MC * sizeof(double) + 16;   // + hand-off counter
@@ -1124,10 +1139,11 @@ __global__ __launch_bounds__(FI_THREADS, 4) void flow_iter_kernel(const FiArgs a
 #else
                 // The lanes hand each other p and q through the row's own LDS words, which only this wave touches
                 // and whose values are in registers by then: p[l] replaces v[2l], q[l] replaces v[2l+1].  A wave's
-                // LDS operations execute in order, so a later read sees an earlier write of another lane; the empty
-                // asm statements keep the compiler from moving a read of one word across the write of another
-                // (to one thread they are unrelated).  8-byte reads and writes cost the LDS pipe 2 and 6 cycles, the
-                // two ds_bpermute of an f64 exchange 4 each: 28 instead of 46 cycles per channel.
+                // LDS operations execute in order, so a later read sees an earlier write of another lane; the reads
+                // are volatile asm statements with a memory clobber, which keeps the compiler from moving the write of
+                // one word across the read of another (to one thread they are unrelated).  8-byte reads and writes
+                // cost the LDS pipe 2 and 6 cycles, the two ds_bpermute of an f64 exchange 4 each: 28 instead of 46
+                // cycles per channel.
                 // The reads are spelled out as ds_read_b64: the compiler would pair them into ds_read2_b64, which takes
                 // the LDS array 8 cycles for two values where two ds_read_b64 take 4 (MI355X_MICROARCH.md, LDS table).
                 // Byte offsets: channel 4096 (FI_G * FI_MC doubles), odd columns 512 (FI_HALF), 7 lanes on 56 (FI_M).
