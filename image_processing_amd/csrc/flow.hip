@@ -31,6 +31,7 @@
 #include <stdlib.h>
 #include <vector>
 #include <type_traits>
+#include <utility>
 
 // Ablation builds (tools/fi_ablate.py, timing only, results are garbage): bit 0 = the consumer waves do no work,
 // bit 1 = the second expansion is sampled from the pair's first frame (its lines are L1 hits), bit 2 = the
@@ -62,6 +63,7 @@ struct LevelGeom {
     // tiled pyramid kernel: the two source columns / rows every level pixel samples (equal in mode 0)
     const int *xs2;      // [lw][2]
     const int *ys2;      // [lh][2]
+    int exact_scale;     // S when W = S lw, H = S lh, S = 4 or 8 and every resize tap is (S d + S/2 - 1, weight 0.5): pyr_exact_kernel
     int tox, toy;        // level pixels per tile
     int src_rows, src_cols, src_pitch, tmp_pitch;   // staged source window (max over tiles) and LDS pitches
     unsigned lds_bytes;
@@ -354,6 +356,150 @@ __global__ __launch_bounds__(256) void pyr_level_kernel(PyrArgs a)
             v = h0 * b0 + h1 * b1;
         }
         a.out[((size_t)f * a.lh + dy) * a.lw + dx] = v;
+    }
+}
+
+// The same level image for the geometry the usual pyramid has at levels 2 and 3: W = S * lw and H = S * lh with S = 4
+// or 8, so that every level pixel is the mean of the blurred image at source columns S dx + S/2 - 1, S dx + S/2 and
+// rows S dy + S/2 - 1, S dy + S/2 (both linear weights are exactly 0.5; launch_level_expansion checks the tables).
+// pyr_level_kernel is generic over scales (run-time tables, lanes = rows, which caps a tile at 64 staged rows and, with
+// its f32 window, at 8 level columns for S = 4): 815 vector instructions per level pixel at S = 4 where the arithmetic
+// needs 200.  Here the tile is TOX x TOY level pixels and nothing is looked up:
+//   1. the source window goes to LDS as f32, one aligned quad of columns per item (reflect-101 outside the frame);
+//   2. row pass: item = (window row, level column), lanes along the columns: the KS + 1 window values of the column
+//      pair are read as aligned 16-byte quads (conflict-free for S = 4), taps left to right as in pyr_level_kernel;
+//   3. column pass + mean: thread = level pixel, the KS + 1 rows of both columns as 8-byte reads, taps paired from the
+//      centre outwards, then (h0 a0 + g0 a1) b0 + (h1 a0 + g1 a1) b1 with a0 = a1 = b0 = b1 = 0.5.
+// Every expression has the operations and the order of pyr_level_kernel<KS> in mode 2; the parity tests compare the
+// level images of both kernels through the flow fields, which stay bit-identical.
+typedef float pyr_f32x4 __attribute__((ext_vector_type(4)));
+typedef float pyr_f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void asm_keep(pyr_f32x2 &v) { asm volatile("" : "+v"(v)); }
+template <int OFF>
+__device__ __forceinline__ void pyr_read_b64(unsigned addr, pyr_f32x2 &v)
+{
+    asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF) : "memory");
+}
+// t[k] = the 8 bytes at addr + k * PITCH for k = 0 .. N-1, waited for
+template <int PITCH, int... K>
+__device__ __forceinline__ void pyr_read_rows(unsigned addr, pyr_f32x2 (&t)[sizeof...(K)], std::integer_sequence<int, K...>)
+{
+    (pyr_read_b64<K * PITCH>(addr, t[K]), ...);
+    asm volatile("s_waitcnt lgkmcnt(0)" : : : "memory");
+    (asm_keep(t[K]), ...);
+}
+template <int KS, int S, int TOX, int TOY>
+__global__ __launch_bounds__(256) void pyr_exact_kernel(PyrArgs a)
+{
+    static_assert((KS == 9 && S == 4) || (KS == 19 && S == 8), "the row pass reads 3 or 6 quads");
+    constexpr int R = KS / 2;
+    constexpr int OFF = (R - S / 2 + 1 + 3) & ~3;                 // window column 0 = source column S dx0 - OFF
+    constexpr int CWN = S * TOX + ((R - S / 2 + OFF + 1 + 3) & ~3); // staged columns (a multiple of 4)
+    constexpr int CW = S == 8 ? CWN + 4 : CWN;                     // pitch: with 8 lanes a row, 32 bytes apart, 84 floats leave the
+                                                                   // 16-byte reads of the row pass two-way conflicts, 80 four-way
+    constexpr int NR = S * (TOY - 1) + 2 + 2 * R;                  // staged rows, first = source row S dy0 + S/2 - 1 - R
+    constexpr int Q0 = S / 2 - 1 - R + OFF;                        // first window value of a column pair, relative to S dxl
+    constexpr int NQ = (Q0 + KS + 1 + 3) / 4;                      // quads read per row-pass item
+    constexpr int TP = 2 * TOX;                                    // row-pass results per window row
+    static_assert(Q0 >= 0 && S * (TOX - 1) + 4 * NQ <= CW, "row-pass reads stay inside the window");
+    __shared__ __align__(16) float s_src[NR * CW];
+    __shared__ __align__(16) float s_tmp[NR * TP];
+    const int tid = threadIdx.x;
+    const int per_frame = a.tiles_x * a.tiles_y, total = per_frame * a.nf, per_xcd = (total + 7) >> 3;
+    const int tk = (int)(blockIdx.x >> 3), tile = (int)(blockIdx.x & 7) * per_xcd + tk;
+    if (tk >= per_xcd || tile >= total) return;
+    const int f = tile / per_frame, trem = tile - f * per_frame;
+    const int tby = trem / a.tiles_x, tbx = trem - tby * a.tiles_x;
+    const int dx0 = tbx * TOX, dy0 = tby * TOY;
+    const int fi = a.first + f;
+    const uint8_t *frame = fi < 0 ? a.extra : a.frames + (size_t)fi * a.H * a.W;
+    const int c_org = S * dx0 - OFF, r_lo = S * dy0 + S / 2 - 1 - R;
+    // 1. window.  (One reflection suffices: a level of this path has at least 32 pixels a side, so the frame has 32 S,
+    // and the window reaches at most R + S / 2 beyond it.  Item -> (row, quad) by stepping, not by division.)
+    {
+        constexpr int QW = CWN / 4, DR = 256 / QW, DQ = 256 % QW;
+        const bool inside = c_org >= 0 && c_org + CWN <= a.W;      // (W is a multiple of 4 on this path)
+        auto refl = [](int p, int len) { return p < 0 ? -p : (p > len - 1 ? 2 * (len - 1) - p : p); };
+        constexpr int NIT = (NR * QW + 255) / 256;
+        int r = tid / QW, q = tid - r * QW;
+        if (inside) {
+            // all of a thread's loads are issued before the first is converted (rolled up, every round would wait
+            // for its own trip to memory)
+            uint32_t d[NIT]; int rr[NIT], qq[NIT];
+#pragma unroll
+            for (int k = 0; k < NIT; ++k) {
+                rr[k] = r; qq[k] = q;
+                const int rc = min(r, NR - 1);
+                d[k] = *reinterpret_cast<const uint32_t *>(frame + (size_t)refl(r_lo + rc, a.H) * a.W + c_org + 4 * q);
+                q += DQ; r += DR;
+                if (q >= QW) { q -= QW; ++r; }
+            }
+#pragma unroll
+            for (int k = 0; k < NIT; ++k)
+                if (rr[k] < NR)
+                    *reinterpret_cast<float4 *>(s_src + rr[k] * CW + 4 * qq[k]) =
+                        make_float4((float)(d[k] & 0xff), (float)((d[k] >> 8) & 0xff), (float)((d[k] >> 16) & 0xff), (float)(d[k] >> 24));
+        } else {
+            while (r < NR) {
+                const uint8_t *row = frame + (size_t)refl(r_lo + r, a.H) * a.W;
+                const int c = c_org + 4 * q;
+                *reinterpret_cast<float4 *>(s_src + r * CW + 4 * q) =
+                    make_float4((float)row[refl(c, a.W)], (float)row[refl(c + 1, a.W)], (float)row[refl(c + 2, a.W)], (float)row[refl(c + 3, a.W)]);
+                q += DQ; r += DR;
+                if (q >= QW) { q -= QW; ++r; }
+            }
+        }
+    }
+    __syncthreads();
+    // 2. row pass
+    for (int i = tid; i < NR * TOX; i += 256) {
+        const int r = i / TOX, dxl = i - r * TOX;
+        // (ds_read_b128 by hand: the compiler splits a float4 read into 4- and 8-byte reads at odd offsets so that the
+        // pairs it multiplies land in aligned registers, and with the lanes 16 or 32 bytes apart those run into
+        // four-way bank conflicts -- the LDS was 91 % busy, 58 % of it conflicts)
+        const unsigned sa = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) float *)(s_src + r * CW + S * dxl);
+        pyr_f32x4 xq[6];
+        asm volatile("ds_read_b128 %0, %1" : "=v"(xq[0]) : "v"(sa) : "memory");
+        asm volatile("ds_read_b128 %0, %1 offset:16" : "=v"(xq[1]) : "v"(sa) : "memory");
+        asm volatile("ds_read_b128 %0, %1 offset:32" : "=v"(xq[2]) : "v"(sa) : "memory");
+        if (NQ > 3) {
+            asm volatile("ds_read_b128 %0, %1 offset:48" : "=v"(xq[3]) : "v"(sa) : "memory");
+            asm volatile("ds_read_b128 %0, %1 offset:64" : "=v"(xq[4]) : "v"(sa) : "memory");
+            asm volatile("ds_read_b128 %0, %1 offset:80" : "=v"(xq[5]) : "v"(sa) : "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(xq[0]), "+v"(xq[1]), "+v"(xq[2]), "+v"(xq[3]), "+v"(xq[4]), "+v"(xq[5]) : : "memory");
+        } else {
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(xq[0]), "+v"(xq[1]), "+v"(xq[2]) : : "memory");
+        }
+        float x[4 * NQ];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) { x[4 * q] = xq[q].x; x[4 * q + 1] = xq[q].y; x[4 * q + 2] = xq[q].z; x[4 * q + 3] = xq[q].w; }
+        float v0 = x[Q0] * a.kt.k[0], v1 = x[Q0 + 1] * a.kt.k[0];
+#pragma unroll
+        for (int k = 1; k < KS; ++k) { v0 += x[Q0 + k] * a.kt.k[k]; v1 += x[Q0 + k + 1] * a.kt.k[k]; }
+        *reinterpret_cast<float2 *>(s_tmp + r * TP + 2 * dxl) = make_float2(v0, v1);
+    }
+    __syncthreads();
+    // 3. column pass + mean
+    for (int i = tid; i < TOX * TOY; i += 256) {
+        const int dyl = i / TOX, dxl = i - dyl * TOX;
+        const int dx = dx0 + dxl, dy = dy0 + dyl;
+        if (dx >= a.lw || dy >= a.lh) continue;
+        // (single ds_read_b64: paired into ds_read2_b64 they take the LDS array twice as long)
+        const unsigned ta = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) float *)(s_tmp + (S * dyl) * TP + 2 * dxl);
+        pyr_f32x2 t[KS + 1];
+        pyr_read_rows<TP * 4>(ta, t, std::make_integer_sequence<int, KS + 1>());
+        float h0 = a.kt.k[R] * t[R].x, h1 = a.kt.k[R] * t[R + 1].x, g0 = a.kt.k[R] * t[R].y, g1 = a.kt.k[R] * t[R + 1].y;
+#pragma unroll
+        for (int j = 1; j <= R; ++j) {
+            h0 += a.kt.k[R + j] * (t[R + j].x + t[R - j].x);
+            h1 += a.kt.k[R + j] * (t[R + 1 + j].x + t[R + 1 - j].x);
+            g0 += a.kt.k[R + j] * (t[R + j].y + t[R - j].y);
+            g1 += a.kt.k[R + j] * (t[R + 1 + j].y + t[R + 1 - j].y);
+        }
+        const float a1 = 0.5f, a0 = 1.f - a1, b1 = 0.5f, b0 = 1.f - b1;
+        h0 = h0 * a0 + g0 * a1;
+        h1 = h1 * a0 + g1 * a1;
+        a.out[((size_t)f * a.lh + dy) * a.lw + dx] = h0 * b0 + h1 * b1;
     }
 }
 
@@ -1384,6 +1530,13 @@ int build_plan(ipx_ctx *ctx, int H, int W)
         std::vector<int> xo, yo; std::vector<float> xa, yb;
         linear_table_x(W, g.lw, xo, xa);
         linear_table_y(H, g.lh, yo, yb);
+        g.exact_scale = 0;
+        for (int sc = 4; sc <= 8 && g.mode == 2 && (W & 3) == 0; sc += 4) {
+            bool ok = W == sc * g.lw && H == sc * g.lh;
+            for (int d = 0; ok && d < g.lw; ++d) ok = xo[d] == sc * d + sc / 2 - 1 && xa[d] == 0.5f;
+            for (int d = 0; ok && d < g.lh; ++d) ok = yo[2 * d] == sc * d + sc / 2 - 1 && yo[2 * d + 1] == sc * d + sc / 2 && yb[d] == 0.5f;
+            if (ok) g.exact_scale = sc;
+        }
         offs[k][0] = push(xo.data(), xo.size() * 4); offs[k][1] = push(xa.data(), xa.size() * 4);
         offs[k][2] = push(yo.data(), yo.size() * 4); offs[k][3] = push(yb.data(), yb.size() * 4);
         // sample columns / rows of every level pixel, all three resize modes in one form
@@ -1492,6 +1645,12 @@ int launch_level_expansion(ipx_ctx *ctx, const LevelGeom &g, const uint8_t *fram
         const dim3 g3((pl->W / 4 + 63) / 64, (pl->H / 4 + 3) / 4, nf);
         if (g.mode == 0) hipLaunchKernelGGL(pyr3_kernel<0>, g3, block, 0, ctx->stream, a);
         else hipLaunchKernelGGL(pyr3_kernel<1>, g3, block, 0, ctx->stream, a);
+    } else if (g.exact_scale == 4 && g.ksize == 9) {
+        a.tiles_x = (g.lw + 31) / 32; a.tiles_y = (g.lh + 7) / 8;
+        hipLaunchKernelGGL((pyr_exact_kernel<9, 4, 32, 8>), dim3(8 * ((a.tiles_x * a.tiles_y * nf + 7) / 8)), block, 0, ctx->stream, a);
+    } else if (g.exact_scale == 8 && g.ksize == 19) {
+        a.tiles_x = (g.lw + 7) / 8; a.tiles_y = (g.lh + 7) / 8;
+        hipLaunchKernelGGL((pyr_exact_kernel<19, 8, 8, 8>), dim3(8 * ((a.tiles_x * a.tiles_y * nf + 7) / 8)), block, 0, ctx->stream, a);
     } else
     switch (g.ksize) {
     case 3: hipLaunchKernelGGL(pyr_level_kernel<3>, grid, block, g.lds_bytes, ctx->stream, a); break;

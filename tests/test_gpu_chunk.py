@@ -84,6 +84,27 @@ def test_farneback_pair_field_fused_level0(eng, shape, shift):
         assert err.max() <= 1e-12 * scale, "%dx%d noise=%s: max |dflow| = %g (flow scale %g)" % (w, h, noise, err.max(), scale)
 
 
+# Sizes with H and W multiples of 8 and at least 256: levels 2 and 3 are then exact quarter / eighth scales and take
+# pyr_exact_kernel (aligned 16-byte window reads, no tables).  White noise, so that every bit of the 9- and 19-tap blurs
+# counts; widths and heights that end inside a tile, a single tile column at level 3, interior tiles with dword loads.
+@pytest.mark.parametrize("shape", [(256, 256), (256, 320), (264, 520), (328, 264), (512, 288)])
+def test_farneback_pair_field_exact_pyramid(eng, shape):
+    from oracle import cref
+    h, w = shape
+    rng = np.random.default_rng(h * 1000 + w)
+    for noise in (True, False):
+        if noise:
+            a = rng.integers(0, 256, (h, w)).astype(np.uint8); b = rng.integers(0, 256, (h, w)).astype(np.uint8)
+        else:
+            a, b = _moving_pair(h + w, h, w, 2.5)
+        ref = cref.farneback(a.astype(np.float32), b.astype(np.float32))
+        got = eng.farneback_pair(eng.to_device(a.astype(np.float32)), eng.to_device(b.astype(np.float32))).cpu().numpy()
+        assert got.shape == ref.shape and np.isfinite(got).all()
+        err = np.abs(got.astype(np.float64) - ref.astype(np.float64))
+        scale = max(1.0, float(np.abs(ref).max()))
+        assert err.max() <= 1e-12 * scale, "%dx%d noise=%s: max |dflow| = %g (flow scale %g)" % (w, h, noise, err.max(), scale)
+
+
 def test_farneback_rejects_non_u8_images(eng):
     from image_processing_amd._ipx import IpxError
     a = np.full((40, 40), 10.5, np.float32)
