@@ -1362,9 +1362,13 @@ __global__ __launch_bounds__(FI_THREADS, 4) void flow_iter_kernel(const FiArgs a
                     msum += (double)(x < w ? m0 : 0.f);           // (adding +0 changes nothing: the sum is never -0)
                     msum += (double)(x + 1 < w ? m1 : 0.f);
                 } else {
+                    // one 16-byte store per lane where the width is even (x is even: x < w then means x + 1 < w, and the
+                    // address is 16-byte aligned).  Under the test x + 1 < w the compiler made two 8-byte stores of it.
                     float2 *dst = fout + (size_t)y * w + x;
-                    if (x + 1 < w && ((w & 1) == 0)) {
-                        *reinterpret_cast<float4 *>(dst) = make_float4(o[0].x, o[0].y, o[1].x, o[1].y);
+                    if ((w & 1) == 0) {
+                        if (x < w) {
+                            *reinterpret_cast<float4 *>(dst) = make_float4(o[0].x, o[0].y, o[1].x, o[1].y);
+                        }
                     } else {
                         if (x < w) dst[0] = o[0];
                         if (x + 1 < w) dst[1] = o[1];
