@@ -20,7 +20,7 @@ OUT = os.path.join(ROOT, "gpurun_out")
 FETCH_FACTOR = 2.0
 
 # kernel symbol -> profiler class name of libipx (api.hip)
-CLASSES = [("flow_iter_kernel", "flow_iter"), ("pyr_level_kernel", "pyr_level"), ("pyr3_kernel", "pyr_level"), ("polyexp_kernel", "polyexp"),
+CLASSES = [("flow_iter_kernel", "flow_iter"), ("pyr_level_kernel", "pyr_level"), ("pyr_exact_kernel", "pyr_level"), ("pyr3_kernel", "pyr_level"), ("polyexp_kernel", "polyexp"),
            ("magnitude_finish_kernel", "magnitude_finish"),
            ("detect_kernel", "detect"), ("persistent_kernel", "persistent"), ("static_maps_kernel", "static_maps"), ("static_maps16_kernel", "static_maps"),
            ("finalize_kernel", "finalize"), ("ccl_merge", "ccl_merge"), ("ccl_init", "ccl_init")]
