@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Randomised parity sweep of the whole path against the CPU oracle (a checker, like tests/): random frame
 sizes (odd ones included), chunk lengths, parameter sets and scene contents.  Run on the GPU box:
-    python tools/fuzz_parity.py [cases] [seed] [max_side] [wide]
+    python tools/fuzz_parity.py [cases] [seed] [max_side] [wide | exact8]
 Prints one line per case and exits non-zero at the first mismatch (the case's seed reproduces it)."""
 import os
 import sys
@@ -65,12 +65,15 @@ def one_case(eng, seed, max_side=260, wide=False):
         params["consecutive_threshold"])
 
 
-def flow_case(eng, seed):
+def flow_case(eng, seed, exact8=False):
     """One Farneback pair of arbitrary content (white noise, constants, steps, shifted textures; sizes from 2x2,
-    so 1 to 4 pyramid levels and every resize path) against the oracle's field, value by value."""
+    so 1 to 4 pyramid levels and every resize path) against the oracle's field, value by value.
+    exact8: sizes that are multiples of 8 from 256 up (levels 2 and 3 are then made by pyr_exact_kernel)."""
     from oracle import cref
     rng = np.random.default_rng(seed)
     h = int(rng.integers(2, 300)); w = int(rng.integers(2, 400))
+    if exact8:
+        h = 8 * int(rng.integers(32, 72)); w = 8 * int(rng.integers(32, 90))
     kind = int(rng.integers(0, 5))
     yy, xx = np.mgrid[0:h, 0:w].astype(np.float64)
     if kind == 0:
@@ -109,6 +112,16 @@ def main():
     wide = len(sys.argv) > 4 and sys.argv[4] == "wide"
     eng = Engine(0)
     t0 = time.time()
+    if len(sys.argv) > 4 and sys.argv[4] == "exact8":         # flow fields only, at sizes that take pyr_exact_kernel
+        for k in range(cases):
+            try:
+                print("seed %d: flow %s  [%.0f s]" % (seed0 + k, flow_case(eng, seed0 + k, True), time.time() - t0), flush=True)
+            except AssertionError as e:
+                print("seed %d: MISMATCH %s" % (seed0 + k, e), flush=True)
+                sys.exit(1)
+        eng.close()
+        print("%d cases passed" % cases)
+        return
     for k in range(cases):
         seed = seed0 + k
         try:
