@@ -525,16 +525,20 @@ __global__ __launch_bounds__(256) void pyr3_kernel(PyrArgs a)
     const int f = blockIdx.z, fi = a.first + f;
     const uint8_t *frame = fi < 0 ? a.extra : a.frames + (size_t)fi * a.H * a.W;
     const float k1 = a.kt.k[1], k2 = a.kt.k[2];
+    const int lane = threadIdx.x & 63;
     float rp[6][4];
 #pragma unroll
     for (int r = 0; r < 6; ++r) {
         const uint8_t *row = frame + (size_t)reflect101(by - 1 + r, a.H) * a.W;
         const uint32_t mid = *reinterpret_cast<const uint32_t *>(row + bx);
+        // the two pixels beside the dword are in the neighbouring lanes' dwords (ds_bpermute: the kernel has no other
+        // LDS traffic); only the first and the last lane of a wave load theirs (18 full loads per thread before)
+        const uint32_t lmid = (uint32_t)__shfl_up((int)mid, 1), rmid = (uint32_t)__shfl_down((int)mid, 1);
         float p[6];
-        p[0] = (float)(bx > 0 ? (int)row[bx - 1] : (int)((mid >> 8) & 0xff));             // reflect-101: column -1 is column 1
+        p[0] = (float)(bx > 0 ? (lane > 0 ? (int)(lmid >> 24) : (int)row[bx - 1]) : (int)((mid >> 8) & 0xff));   // reflect-101: column -1 is column 1
         p[1] = (float)(mid & 0xff); p[2] = (float)((mid >> 8) & 0xff);
         p[3] = (float)((mid >> 16) & 0xff); p[4] = (float)(mid >> 24);
-        p[5] = (float)(bx + 4 < a.W ? (int)row[bx + 4] : (int)((mid >> 16) & 0xff));      // column W is column W-2
+        p[5] = (float)(bx + 4 < a.W ? (lane < 63 ? (int)(rmid & 0xff) : (int)row[bx + 4]) : (int)((mid >> 16) & 0xff));   // column W is column W-2
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             float v = p[c + 1] * k1;
