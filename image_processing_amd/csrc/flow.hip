@@ -584,7 +584,7 @@ template <bool FUSED>
 __global__ __launch_bounds__(256) void polyexp_kernel(const float *I, int h, int w, int tiles_x, int tiles_y, int nf, PolyConst pc, float *R, PxSrc src)
 {
     __shared__ __align__(16) float s_in[PX_SH * PX_IP];
-    __shared__ __align__(16) float s_t[3][PX_TH][PX_SP];
+    __shared__ __align__(16) float s_t[PX_TH][3][PX_SP];   // [row][t0 | t1 | t2][column]: the three planes of a row within one read offset range
     const int tid = threadIdx.x;
     const int per_frame = tiles_x * tiles_y, total = per_frame * nf, per_xcd = (total + 7) >> 3;
     const int k = (int)(blockIdx.x >> 3);
@@ -712,7 +712,7 @@ __global__ __launch_bounds__(256) void polyexp_kernel(const float *I, int h, int
             t1 = t1 + pc.xg[j] * (s1 - s0);
             t2 = t2 + pc.xxg[j] * p;
         }
-        s_t[0][r][c] = t0; s_t[1][r][c] = t1; s_t[2][r][c] = t2;
+        s_t[r][0][c] = t0; s_t[r][1][c] = t1; s_t[r][2][c] = t2;
     };
     {
         static_assert(PX_TH == 16 && PX_TW == 64, "four waves x four consecutive rows x 64 columns");
@@ -743,7 +743,7 @@ __global__ __launch_bounds__(256) void polyexp_kernel(const float *I, int h, int
     for (int r = tid >> 6; r < PX_TH; r += 4) {
         const int y = y0 + r;
         if (y >= h) break;
-        const float *r0 = s_t[0][r] + lane + POLY_N, *r1 = s_t[1][r] + lane + POLY_N, *r2 = s_t[2][r] + lane + POLY_N;
+        const float *r0 = s_t[r][0] + lane + POLY_N, *r1 = s_t[r][1] + lane + POLY_N, *r2 = s_t[r][2] + lane + POLY_N;
         double b1 = r0[0] * pc.g[0], b2 = 0, b3 = r1[0] * pc.g[0], b4 = 0, b5 = r2[0] * pc.g[0], b6 = 0;
 #pragma unroll
         for (int j = 1; j <= POLY_N; ++j) {
