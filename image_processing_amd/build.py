@@ -16,7 +16,10 @@ CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libipx.so")
 SOURCES = ["api.hip", "detect.hip", "temporal.hip", "ccl.hip", "flow.hip", "chunk.hip", "group.hip"]
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
+# -fno-slp-vectorize: the SLP vectoriser turns pairs of f32 operations into packed instructions (v_pk_mul_f32 ...),
+# which on this chip cost what they save or more (measured A/B: polyexp -1.4 %, pyramids -3.4 %, flow_iter -0.4 % without
+# them; a hand-packed horizontal pass of polyexp, 11 % fewer instructions, was 10 % slower).  No effect on results.
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-fno-slp-vectorize",
          "-fvisibility=hidden", "-Wall", "-Wno-unused-result"]
 
 
