@@ -15,7 +15,10 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libipx.so")
-SOURCES = ["api.hip", "detect.hip", "temporal.hip", "ccl.hip", "flow.hip", "chunk.hip", "group.hip"]
+SOURCES = ["api.hip", "detect.hip", "temporal.hip", "ccl.hip", "flow.hip", "flow_iter.hip", "chunk.hip", "group.hip"]
+# per-file flags: the marching kernel is 1.5 % faster under the scheduler that maximises instruction-level parallelism,
+# polyexp_kernel (flow.hip) 7 % slower (measured A/B on one box)
+EXTRA_FLAGS = {"flow_iter.hip": ["-mllvm", "-amdgpu-sched-strategy=max-ilp"]}
 # -fno-slp-vectorize: the SLP vectoriser turns pairs of f32 operations into packed instructions (v_pk_mul_f32 ...),
 # which on this chip cost what they save or more (measured A/B: polyexp -1.4 %, pyramids -3.4 %, flow_iter -0.4 % without
 # them; a hand-packed horizontal pass of polyexp, 11 % fewer instructions, was 10 % slower).  No effect on results.
@@ -57,14 +60,14 @@ def _check_isa(verbose=False):
 def build_lib(force=False, verbose=False):
     """Compile every HIP translation unit to an object (in parallel) and link libipx.so."""
     os.makedirs(LIBDIR, exist_ok=True)
-    headers = [os.path.join(CSRC, "ipx_internal.h"), os.path.join(HERE, "..", "include", "ipx.h")]
+    headers = [os.path.join(CSRC, "ipx_internal.h"), os.path.join(CSRC, "flow_iter.h"), os.path.join(HERE, "..", "include", "ipx.h")]
     objs, procs = [], []
     for s in SOURCES:
         src = os.path.join(CSRC, s)
         obj = os.path.join(LIBDIR, s.replace(".hip", ".o"))
         objs.append(obj)
         if force or _stale(obj, [src] + headers):
-            cmd = [_hipcc()] + FLAGS + ["-c", src, "-o", obj]
+            cmd = [_hipcc()] + FLAGS + EXTRA_FLAGS.get(s, []) + ["-c", src, "-o", obj]
             if verbose:
                 print(" ".join(cmd))
             procs.append((s, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))

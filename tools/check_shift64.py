@@ -106,7 +106,7 @@ def check_library():
     flags = [f for f in b.FLAGS if f not in ("-fPIC",)]
     bad = []
     for s in b.SOURCES:
-        asm = compile_to_asm(os.path.join(b.CSRC, s), flags, b._hipcc())                                  # the build's compiler
+        asm = compile_to_asm(os.path.join(b.CSRC, s), flags + b.EXTRA_FLAGS.get(s, []), b._hipcc())                                  # the build's compiler
         bad += [(s,) + x for x in check_asm(asm)]
         bad += [(s, name, 0, "uses %d bytes of private (scratch) memory per lane" % nbytes) for name, nbytes in check_scratch(asm)]
     return bad

@@ -26,7 +26,7 @@ def build():
     objs = []
     for s in b.SOURCES:
         obj = os.path.join(LIBDIR, s.replace(".hip", ".o"))
-        subprocess.check_call([b._hipcc()] + b.FLAGS + ["-DIPX_FI_STAMPS", "-c", os.path.join(b.CSRC, s), "-o", obj])
+        subprocess.check_call([b._hipcc()] + b.FLAGS + b.EXTRA_FLAGS.get(s, []) + ["-DIPX_FI_STAMPS", "-c", os.path.join(b.CSRC, s), "-o", obj])
         objs.append(obj)
     subprocess.check_call([b._hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs)
     print(LIB)
