@@ -3,13 +3,13 @@
 #include <hip/hip_runtime.h>
 #include <stddef.h>
 
+#ifndef IPX_FI_C_BPERMUTE
+#define IPX_FI_C_BPERMUTE 0      // 1: phase C exchanges its pair and quad sums with ds_bpermute (the round-2 form)
+#endif
 // Ablation builds (tools/fi_ablate.py, timing only, results are garbage): bit 0 = the consumer waves do no work,
 // bit 1 = the second expansion is sampled from the pair's first frame (its lines are L1 hits), bit 2 = the
 // producers replace the matrix arithmetic by plain sums of what they loaded, bit 3 = one of the four bilinear taps
 // is loaded (44 instead of 108 bytes per matrix pixel through L1).
-#ifndef IPX_FI_C_BPERMUTE
-#define IPX_FI_C_BPERMUTE 0      // 1: phase C exchanges its pair and quad sums with ds_bpermute (the round-2 form)
-#endif
 #ifndef IPX_FI_ABLATE
 #define IPX_FI_ABLATE 0
 #endif
