@@ -45,6 +45,9 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t ipx_make_rsrc(const void *base
 // 4 * UM_DEAD is beyond the resource for frames of up to 2^23 pixels and a harmless read inside it for larger
 // ones -- what such a load returns is never used.  The +16 / +1 row steps come after the select, so they fold
 // into the instructions' immediate offsets or cost one addition for both planes.
+// The expansions are loaded with the default cache policy: marked non-temporal, the loads of the pair's first frame
+// cost the kernel 6 % and the bilinear taps 48 % (measured A/B) -- every line is wanted again, by the neighbouring
+// taps and by the pair that follows.
 typedef unsigned int ipx_u32x4 __attribute__((ext_vector_type(4)));
 constexpr unsigned UM_DEAD = 0x0f000000u;
 __device__ __forceinline__ void um_load(__amdgpu_buffer_rsrc_t rR, unsigned FS, unsigned P16, float2 d, int x, int y, int h, int w,
@@ -265,7 +268,9 @@ __global__ __launch_bounds__(FI_THREADS, 4) void flow_iter_kernel(const FiArgs a
     auto vec_issue_t = [&](const FiRow &t) {
         FiVec v;
         if (IN == 0) {
-            v.p00 = fin[(size_t)t.row * w + ax];
+            typedef float fi_f2 __attribute__((ext_vector_type(2)));
+            const fi_f2 lv = __builtin_nontemporal_load(reinterpret_cast<const fi_f2 *>(fin + (size_t)t.row * w + ax));
+            v.p00 = make_float2(lv.x, lv.y);
         } else if (IN == 2) {
             const float2 *S0 = fin + (size_t)t.o0 * a.sw, *S1 = fin + (size_t)t.o1 * a.sw;
             v.b1 = t.b1;
@@ -592,7 +597,12 @@ __global__ __launch_bounds__(FI_THREADS, 4) void flow_iter_kernel(const FiArgs a
                     float2 *dst = fout + (size_t)y * w + x;
                     if ((w & 1) == 0) {
                         if (x < w) {
-                            *reinterpret_cast<float4 *>(dst) = make_float4(o[0].x, o[0].y, o[1].x, o[1].y);
+                            // (non-temporal, like the load of the field in vec_issue_t: an iteration's field is read by the
+                            // next one 10 ms later, by which time no cache holds it; marked so, it leaves the L2 to the
+                            // expansions, each of which a second pair reads: -1 % on the kernel, measured A/B)
+                            typedef float fi_f4 __attribute__((ext_vector_type(4)));
+                            const fi_f4 ov = {o[0].x, o[0].y, o[1].x, o[1].y};
+                            __builtin_nontemporal_store(ov, reinterpret_cast<fi_f4 *>(dst));
                         }
                     } else {
                         if (x < w) dst[0] = o[0];
