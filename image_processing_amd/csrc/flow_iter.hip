@@ -188,6 +188,20 @@ __device__ __forceinline__ double fi_lane_f64(double v, int addr)
 }
 #endif
 
+// 1 / x for a normal x of modest exponent, correctly rounded: the steps of the compiler's IEEE division of 1.0 by x
+// that remain when nothing needs scaling (see phase C)
+__device__ __forceinline__ bool fi_is_normal(double x) { return __builtin_amdgcn_class(x, 0x108); }   // +-normal
+__device__ __forceinline__ double fi_rcp_normal(double x)
+{
+    double y = __builtin_amdgcn_rcp(x);
+    double e = __builtin_fma(-x, y, 1.0);
+    y = __builtin_fma(e, y, y);
+    e = __builtin_fma(-x, y, 1.0);
+    y = __builtin_fma(e, y, y);
+    e = __builtin_fma(-x, y, 1.0);          // residual of the quotient q = 1.0 * y
+    return __builtin_fma(e, y, y);
+}
+
 // workgroup barrier that orders LDS traffic only: global loads stay in flight across it
 __device__ __forceinline__ void fi_barrier()
 {
@@ -574,13 +588,27 @@ __global__ __launch_bounds__(FI_THREADS, 4) void flow_iter_kernel(const FiArgs a
 #endif
                 const double scale = 1.0 / (double)((2 * FI_M + 1) * (2 * FI_M + 1));
                 float2 o[2];
+                double g[2][5], det[2], idet[2];
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
-                    const double g11 = acc[j][0] * scale, g12 = acc[j][1] * scale, g22 = acc[j][2] * scale,
-                                 h1 = acc[j][3] * scale, h2 = acc[j][4] * scale;
-                    const double idet = 1. / (g11 * g22 - g12 * g12 + 1e-3);
-                    o[j].x = (float)((g11 * h2 - g12 * h1) * idet);
-                    o[j].y = (float)((g22 * h1 - g12 * h2) * idet);
+#pragma unroll
+                    for (int ch = 0; ch < 5; ++ch) g[j][ch] = acc[j][ch] * scale;
+                    det[j] = g[j][0] * g[j][2] - g[j][1] * g[j][1] + 1e-3;
+                }
+                // 1 / det.  The determinant is built from f32 matrix entries (|det| < 2^273) and is almost always a normal
+                // number; for such a divisor the IEEE division the compiler emits (v_div_scale, v_rcp, two Newton steps,
+                // quotient, residual, v_div_fmas, v_div_fixup: 11 instructions) scales nothing and fixes nothing up, and
+                // fi_rcp_normal is the same arithmetic without those steps (7 instructions, the same bits).  A wave in
+                // which some lane holds a zero, a denormal, an infinity or a NaN takes the division.
+                if (__builtin_amdgcn_ballot_w64(!(fi_is_normal(det[0]) && fi_is_normal(det[1]))) == 0) {
+                    idet[0] = fi_rcp_normal(det[0]); idet[1] = fi_rcp_normal(det[1]);
+                } else {
+                    idet[0] = 1. / det[0]; idet[1] = 1. / det[1];
+                }
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    o[j].x = (float)((g[j][0] * g[j][4] - g[j][1] * g[j][3]) * idet[j]);
+                    o[j].y = (float)((g[j][2] * g[j][3] - g[j][1] * g[j][4]) * idet[j]);
                 }
                 const int x = l < FI_TW / 2 ? x0 + 2 * l : w;     // lanes 57-63 own no output
                 // both solves are finished before anything is stored: left to itself the compiler moves the second one
