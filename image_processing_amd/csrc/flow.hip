@@ -728,7 +728,9 @@ __global__ __launch_bounds__(256) void polyexp_kernel(const float *I, int h, int
     const int lane = tid & 63, x = x0 + lane;
     if (x >= w) return;
     const size_t P = (size_t)h * w;
-    for (int r = tid >> 6; r < PX_TH; r += 4) {
+    const unsigned P16 = (unsigned)(P * 16);
+    const __amdgpu_buffer_rsrc_t rO = ipx_make_rsrc(R + (size_t)f * r_stride(P), (unsigned)(r_stride(P) * 4));
+    for (int r = __builtin_amdgcn_readfirstlane(tid >> 6); r < PX_TH; r += 4) {
         const int y = y0 + r;
         if (y >= h) break;
         const float *r0 = s_t[r][0] + lane + POLY_N, *r1 = s_t[r][1] + lane + POLY_N, *r2 = s_t[r][2] + lane + POLY_N;
@@ -744,19 +746,14 @@ __global__ __launch_bounds__(256) void polyexp_kernel(const float *I, int h, int
             b6 += (r1[j] - r1[-j]) * pc.xg[j];
             b5 += (r2[j] + r2[-j]) * g0;
         }
-        // expansion of a frame: a float4 plane (coefficients 0-3) followed by a float plane (coefficient 4)
-        float *fr = R + (size_t)f * r_stride(P);
-        const size_t o = (size_t)y * w + x;
-        if (FUSED) {                                         // level 0: 21 GB per batch that nothing reads before every cache has turned over
-            typedef float px_f4 __attribute__((ext_vector_type(4)));
-            const px_f4 ov = {(float)(b3 * pc.ig11), (float)(b2 * pc.ig11), (float)(b1 * pc.ig03 + b5 * pc.ig33), (float)(b1 * pc.ig03 + b4 * pc.ig33)};
-            __builtin_nontemporal_store(ov, reinterpret_cast<px_f4 *>(fr + 4 * o));
-            __builtin_nontemporal_store((float)(b6 * pc.ig55), fr + 4 * P + o);
-            continue;
-        }
-        *reinterpret_cast<float4 *>(fr + 4 * o) = make_float4((float)(b3 * pc.ig11), (float)(b2 * pc.ig11),
-                                                             (float)(b1 * pc.ig03 + b5 * pc.ig33), (float)(b1 * pc.ig03 + b4 * pc.ig33));
-        fr[4 * P + o] = (float)(b6 * pc.ig55);
+        // expansion of a frame: a float4 plane (coefficients 0-3) followed by a float plane (coefficient 4).  Stored through
+        // the frame's buffer: column in the vector offset, row (uniform over the wave) in the scalar offset, no address
+        // arithmetic.  Level 0 is 21 GB per batch that nothing reads before every cache has turned over: non-temporal (2).
+        const unsigned row = (unsigned)(y * w);
+        const ipx_u32x4 ov = {__float_as_uint((float)(b3 * pc.ig11)), __float_as_uint((float)(b2 * pc.ig11)),
+                              __float_as_uint((float)(b1 * pc.ig03 + b5 * pc.ig33)), __float_as_uint((float)(b1 * pc.ig03 + b4 * pc.ig33))};
+        ipx_buffer_store_b128<FUSED ? 2 : 0>(ov, rO, 16u * (unsigned)x, 16u * row);
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint((float)(b6 * pc.ig55)), rO, 4u * (unsigned)x, P16 + 4u * row, FUSED ? 2 : 0);
     }
 }
 

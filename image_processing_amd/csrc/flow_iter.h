@@ -14,6 +14,27 @@
 #define IPX_FI_ABLATE 0
 #endif
 
+// raw buffer addressing (an SGPR resource, a 32-bit vector offset that alone is range-checked, a scalar offset)
+typedef unsigned int ipx_u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int ipx_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t ipx_make_rsrc(const void *base, unsigned bytes)
+{
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, (int)bytes, 0x00020000);
+}
+
+// A 16-byte buffer store with a register as scalar offset.  For this form the compiler keeps no distance between the store and
+// a following write to its data registers (the hazard of stores wider than 8 bytes, which it does honour when the scalar offset
+// is a constant); on gfx950 the distance is needed all the same: polyexp_kernel, whose next instruction overwrote the data,
+// stored garbage in every launch of more than about one workgroup per CU (tests/test_gpu_chunk.py: 270 x 480 and larger).
+template <int AUX>
+__device__ __forceinline__ void ipx_buffer_store_b128(ipx_u32x4 v, __amdgpu_buffer_rsrc_t r, unsigned voffset, unsigned soffset)
+{
+    __builtin_amdgcn_raw_buffer_store_b128(v, r, voffset, soffset, AUX);
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_nop 1");
+    __builtin_amdgcn_sched_barrier(0);
+}
+
 // floats per frame of an expansion: 5 per pixel, rounded up so that every frame's float4 plane is 16-byte aligned
 __host__ __device__ inline size_t r_stride(size_t P) { return (5 * P + 3) & ~(size_t)3; }
 

@@ -30,11 +30,6 @@ __device__ __forceinline__ bool um_position(float2 d, int x, int y, int h, int w
 
 // Buffer addressing (SGPR resource + SGPR plane offset + one 32-bit VGPR offset per position) keeps the
 // address arithmetic of the 16 loads of a matrix pixel out of the vector ALU and out of the VGPR file.
-typedef unsigned int ipx_u32x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t ipx_make_rsrc(const void *base, unsigned bytes)
-{
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, (int)bytes, 0x00020000);
-}
 
 // rR: the expansions of the pair's two frames (layout: polyexp_kernel), FS = bytes per frame, P16 = byte
 // offset of the fifth coefficient's plane.  16-byte loads fetch coefficients 0-3 of one pixel; the loads are
@@ -45,10 +40,12 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t ipx_make_rsrc(const void *base
 // 4 * UM_DEAD is beyond the resource for frames of up to 2^23 pixels and a harmless read inside it for larger
 // ones -- what such a load returns is never used.  The +16 / +1 row steps come after the select, so they fold
 // into the instructions' immediate offsets or cost one addition for both planes.
+// (Measured A/B, round 2: with the row's share of every offset moved into the loads' scalar offsets -- 16 of the producers'
+// 210 vector instructions per step fewer -- and the field loaded and stored through buffers the same way, the kernel took the
+// same time to within 0.3 %: the producers have slack, the consumer waves set the pace.)
 // The expansions are loaded with the default cache policy: marked non-temporal, the loads of the pair's first frame
 // cost the kernel 6 % and the bilinear taps 48 % (measured A/B) -- every line is wanted again, by the neighbouring
 // taps and by the pair that follows.
-typedef unsigned int ipx_u32x4 __attribute__((ext_vector_type(4)));
 constexpr unsigned UM_DEAD = 0x0f000000u;
 __device__ __forceinline__ void um_load(__amdgpu_buffer_rsrc_t rR, unsigned FS, unsigned P16, float2 d, int x, int y, int h, int w,
                                         UmIn &in, bool live = true)

@@ -135,6 +135,23 @@ _Zgood:
 		.amdhsa_private_segment_fixed_size 24
 """
     assert mod.check_scratch(spills) == [("_Zspills", 64)]
+    # and kernels with a wide buffer store through a register scalar offset that no wait state follows (on gfx950 a write to
+    # the data registers right behind such a store reaches memory: csrc/flow_iter.h, ipx_buffer_store_b128)
+    stores = """
+_Zstores:
+\tbuffer_store_dwordx4 v[4:7], v0, s[44:47], s52 offen nt
+\tv_mul_f64 v[4:5], v[8:9], s[30:31]
+\tbuffer_store_dwordx4 v[4:7], v0, s[44:47], 0 offen
+\tv_mov_b32 v4, 0
+\tbuffer_store_dwordx4 v[8:11], v0, s[44:47], s5 offen
+\t; sched_barrier mask(0x00000000)
+\ts_nop 1
+\tbuffer_store_dwordx2 v[4:5], v0, s[44:47], s5 offen
+\ts_endpgm
+\t.amdhsa_kernel _Zstores
+\t\t.amdhsa_next_free_vgpr 12
+"""
+    assert mod.check_wide_stores(stores) == [("_Zstores", "buffer_store_dwordx4 v[4:7], v0, s[44:47], s52 offen nt")]
     assert mod.check_library() == []
 
 

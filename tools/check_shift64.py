@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Build-time guard against a gfx950 / hipcc 7.2 problem measured in round 1 (tools/hwtest/seg_loop.hip):
+"""Build-time guards against gfx950 / hipcc 7.2 problems that were measured here (the first in round 1, tools/hwtest/seg_loop.hip;
+check_wide_stores and check_scratch further down say what they guard):
 
 a 64-bit vector shift whose shift-amount VGPR is the LAST register of the wave's allocation (the kernel's
 next_free_vgpr is a multiple of the allocation granule and the amount sits in next_free_vgpr - 1) sometimes
@@ -91,6 +92,24 @@ def check_scratch(asm_text):
     return bad
 
 
+# A buffer store of more than 8 bytes whose scalar offset is a REGISTER: the compiler leaves no distance between it and a
+# following write to its data registers (it does for a constant scalar offset), and on gfx950 the store then writes the new
+# contents (round 2: polyexp_kernel stored garbage in launches of more than about one workgroup per CU).  Such a store must be
+# followed by a wait state: ipx_buffer_store_b128 (csrc/flow_iter.h) issues `s_nop 1` behind it.
+WIDE_STORE = re.compile(r"\s*buffer_store_dwordx[34]\s+v\[\d+:\d+\],\s*\S+,\s*s\[\d+:\d+\],\s*(s\d+|m0|vcc_lo|vcc_hi|ttmp\d+)\b")
+
+
+def check_wide_stores(asm_text):
+    """[(kernel, line)] for wide buffer stores with a register scalar offset that no s_nop follows."""
+    bad = []
+    for name, body, _ in kernels_of(asm_text):
+        code = [l for l in body if l.strip() and not l.strip().startswith(";")]
+        for i, line in enumerate(code):
+            if WIDE_STORE.match(line) and not (i + 1 < len(code) and code[i + 1].strip().startswith("s_nop")):
+                bad.append((name, line.strip()))
+    return bad
+
+
 def compile_to_asm(src, flags, hipcc="/opt/rocm/bin/hipcc"):
     with tempfile.TemporaryDirectory() as td:
         out = os.path.join(td, "k.s")
@@ -109,6 +128,7 @@ def check_library():
         asm = compile_to_asm(os.path.join(b.CSRC, s), flags + b.EXTRA_FLAGS.get(s, []), b._hipcc())                                  # the build's compiler
         bad += [(s,) + x for x in check_asm(asm)]
         bad += [(s, name, 0, "uses %d bytes of private (scratch) memory per lane" % nbytes) for name, nbytes in check_scratch(asm)]
+        bad += [(s, name, 0, "no wait state behind a wide buffer store with a register scalar offset: " + line) for name, line in check_wide_stores(asm)]
     return bad
 
 
