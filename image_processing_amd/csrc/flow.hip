@@ -597,17 +597,36 @@ __global__ __launch_bounds__(256) void polyexp_kernel(const float *I, int h, int
         static_assert(NQ * QROWS == 240, "20 quads x 12 rows per round");
         const int sq = tid % NQ, se0 = tid / NQ;
         const bool sact = tid < NQ * QROWS;
+        // rows y0 - 6 .. y0 + 21 inside the image: no reflection in the row pass, no replication in the column pass
+        const bool yin = y0 >= POLY_N + 1 && y0 + PX_TH + POLY_N <= h - 1;
         if (x0 >= 8 && x0 + PX_IP - 8 <= w) {                   // (w is a multiple of 4 on this path)
             constexpr int NIT = (ER + QROWS - 1) / QROWS;
+            static_assert(NIT == 3 && 2 * QROWS <= ER - 1, "rows e0, e0 + 12 exist for every thread (e0 <= 12), the third is clamped");
             uint32_t mid[NIT]; int lft[NIT], rgt[NIT];
             const int x = x0 - 8 + 4 * sq;
+            if (yin) {
+                // The frame as a buffer: the thread's column and first row in the vector offset, the tile's row and the 12 rows
+                // between a thread's items in the scalar offset -- the twelve loads of a thread share two vector offsets.
+                const __amdgpu_buffer_rsrc_t rI = ipx_make_rsrc(frame, (unsigned)(h * w));
+                const unsigned srow = (unsigned)((y0 - POLY_N - 1) * w);
+                const unsigned dr = x + 4 < w ? 5u : (unsigned)(w - 1 - x);          // right neighbour, from x - 1 (column w is column w - 2)
+                const unsigned v01 = (unsigned)(se0 * w + x - 1), v2 = (unsigned)(min(se0 + 2 * QROWS, ER - 1) * w + x - 1);
 #pragma unroll
-            for (int k = 0; k < NIT; ++k) {
-                const int e = min(se0 + QROWS * k, ER - 1);      // (spare lanes repeat the last row)
-                const uint8_t *row = frame + (size_t)reflect101(y0 - POLY_N - 1 + e, h) * w;
-                mid[k] = *reinterpret_cast<const uint32_t *>(row + x);
-                lft[k] = row[x - 1];                            // x0 >= 64 here
-                rgt[k] = row[x + 4 < w ? x + 4 : w - 2];        // reflect-101: column w is column w - 2
+                for (int k = 0; k < NIT; ++k) {
+                    const unsigned vo = k < 2 ? v01 : v2, so = k < 2 ? srow + (unsigned)(k * QROWS * w) : srow;
+                    lft[k] = (int)__builtin_amdgcn_raw_buffer_load_b8(rI, vo, so, 0);
+                    mid[k] = __builtin_amdgcn_raw_buffer_load_b32(rI, vo + 1u, so, 0);
+                    rgt[k] = (int)__builtin_amdgcn_raw_buffer_load_b8(rI, vo + dr, so, 0);
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < NIT; ++k) {
+                    const int e = min(se0 + QROWS * k, ER - 1);      // (spare lanes repeat the last row)
+                    const uint8_t *row = frame + (size_t)reflect101(y0 - POLY_N - 1 + e, h) * w;
+                    mid[k] = *reinterpret_cast<const uint32_t *>(row + x);
+                    lft[k] = row[x - 1];                            // x0 >= 64 here
+                    rgt[k] = row[x + 4 < w ? x + 4 : w - 2];        // reflect-101: column w is column w - 2
+                }
             }
 #pragma unroll
             for (int k = 0; k < NIT; ++k) {
@@ -636,6 +655,25 @@ __global__ __launch_bounds__(256) void polyexp_kernel(const float *I, int h, int
         __syncthreads();
         // column pass at the window's rows (replicated beyond the image): window row r <-> image row yc, row-pass rows
         // e = yc - (y0 - 6) and its two neighbours
+        if (yin) {
+            // window row r = row-pass rows r, r + 1, r + 2: fixed offsets from the thread's first item
+            const float *mb = s_rp + (se0 + 1) * PX_IP + 4 * sq;
+            float *ob = s_in + se0 * PX_IP + 4 * sq;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                if (sact && se0 + QROWS * k < PX_SH) {
+                    const float *mrow = mb + k * QROWS * PX_IP;
+                    const float4 up = *reinterpret_cast<const float4 *>(mrow - PX_IP), md = *reinterpret_cast<const float4 *>(mrow),
+                                 dn = *reinterpret_cast<const float4 *>(mrow + PX_IP);
+                    float4 o;
+                    o.x = k1 * md.x; o.x += k2 * (dn.x + up.x);
+                    o.y = k1 * md.y; o.y += k2 * (dn.y + up.y);
+                    o.z = k1 * md.z; o.z += k2 * (dn.z + up.z);
+                    o.w = k1 * md.w; o.w += k2 * (dn.w + up.w);
+                    *reinterpret_cast<float4 *>(ob + k * QROWS * PX_IP) = o;
+                }
+            }
+        } else
         for (int r = se0; sact && r < PX_SH; r += QROWS) {
             const int q = sq;
             int yc = y0 - POLY_N + r;
