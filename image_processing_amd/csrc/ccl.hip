@@ -236,39 +236,57 @@ __device__ __forceinline__ uint64_t mword(const uint64_t *bp, const Plane &pl, i
 {
     return (y >= 0 && y < pl.H && k >= 0 && k < pl.wpr) ? bp[(size_t)y * pl.wpr + k] : 0ull;
 }
-__device__ __forceinline__ uint64_t dilated_word(const uint64_t *bp, const Plane &pl, int y, int k)
+// One thread closes CC_RB consecutive rows of one word column: the words of its column and of the two neighbouring columns
+// are loaded once for rows y0-2 .. y0+CC_RB+1 (3 (CC_RB + 4) loads for CC_RB outputs; a thread per word loaded 25 and divided
+// twice).  Of the neighbouring columns' dilated words the erosion needs one bit each, which those loads determine:
+//   bit 63 of dilated(y, k-1) = l63 | l62 | c0 | (row above, column k-1)63 | (row below, column k-1)63
+//   bit 0  of dilated(y, k+1) = r0 | r1 | c63 | (row above, column k+1)0 | (row below, column k+1)0
+// Workgroup: 32 word columns x 8 row groups; grid (columns / 32, rows / (8 CC_RB), planes).
+constexpr int CC_RB = 4;
+__global__ __launch_bounds__(256) void close_cross3_kernel(const uint64_t *bits, Plane pl, int count, const uint8_t *keep, uint64_t *out)
 {
-    if (y < 0 || y >= pl.H || k < 0 || k >= pl.wpr) return 0ull;
-    const uint64_t c = mword(bp, pl, y, k);
-    const uint64_t l = mword(bp, pl, y, k - 1), r = mword(bp, pl, y, k + 1);
-    uint64_t d = c | (c << 1) | (l >> 63) | (c >> 1) | (r << 63) | mword(bp, pl, y - 1, k) | mword(bp, pl, y + 1, k);
-    const int valid = pl.W - 64 * k;                 // clip to the image
-    if (valid < 64) d &= (1ull << valid) - 1;
-    return d;
-}
-__global__ void close_cross3_kernel(const uint64_t *bits, Plane pl, int count, const uint8_t *keep, uint64_t *out)
-{
-    const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= pl.words * count) return;
-    const size_t plane = g / pl.words;
-    if (keep && !keep[plane]) { out[g] = 0; return; }
-    const int w = (int)(g - plane * pl.words);
-    const int y = w / pl.wpr, k = w - y * pl.wpr;
+    const int k = (int)blockIdx.x * 32 + (int)(threadIdx.x & 31);
+    const int y0 = ((int)blockIdx.y * 8 + (int)(threadIdx.x >> 5)) * CC_RB;
+    const size_t plane = blockIdx.z;
+    if (k >= pl.wpr || y0 >= pl.H || plane >= (size_t)count) return;
+    uint64_t *op = out + plane * pl.words;
+    if (keep && !keep[plane]) {
+        for (int r = 0; r < CC_RB && y0 + r < pl.H; ++r) op[(size_t)(y0 + r) * pl.wpr + k] = 0;
+        return;
+    }
     const uint64_t *bp = bits + plane * pl.words;
-    const uint64_t d = dilated_word(bp, pl, y, k);
-    // erosion: out-of-image neighbours count as set
-    const int valid = pl.W - 64 * k;
+    uint64_t L[CC_RB + 4], C[CC_RB + 4], R[CC_RB + 4];            // index j <-> row y0 - 2 + j
+#pragma unroll
+    for (int j = 0; j < CC_RB + 4; ++j) {
+        const int y = y0 - 2 + j;
+        L[j] = mword(bp, pl, y, k - 1); C[j] = mword(bp, pl, y, k); R[j] = mword(bp, pl, y, k + 1);
+    }
+    const int valid = pl.W - 64 * k;                               // clip to the image
     const uint64_t vmask = valid < 64 ? (1ull << valid) - 1 : ~0ull;
-    const uint64_t dl = k > 0 ? dilated_word(bp, pl, y, k - 1) >> 63 : 1ull;
-    uint64_t dr;
-    if (valid <= 64) dr = 0;                          // right neighbour of the last column is outside
-    else dr = dilated_word(bp, pl, y, k + 1) << 63;
-    uint64_t right = (d >> 1) | dr;
-    if (valid <= 64) right |= 1ull << (valid - 1);   // pixel W-1 looks right at "outside" = set
-    const uint64_t leftn = (d << 1) | dl;
-    const uint64_t upn = y > 0 ? dilated_word(bp, pl, y - 1, k) : ~0ull;
-    const uint64_t dnn = y + 1 < pl.H ? dilated_word(bp, pl, y + 1, k) : ~0ull;
-    out[g] = d & leftn & right & upn & dnn & vmask;
+    uint64_t D[CC_RB + 2];                                          // dilated words of rows y0-1 .. y0+CC_RB (index i <-> row y0 - 1 + i)
+#pragma unroll
+    for (int i = 0; i < CC_RB + 2; ++i) {
+        const int y = y0 - 1 + i, j = i + 1;
+        const uint64_t c = C[j];
+        const uint64_t d = (c | (c << 1) | (L[j] >> 63) | (c >> 1) | (R[j] << 63) | C[j - 1] | C[j + 1]) & vmask;
+        D[i] = (y >= 0 && y < pl.H) ? d : 0ull;
+    }
+#pragma unroll
+    for (int r = 0; r < CC_RB; ++r) {
+        const int y = y0 + r, i = r + 1, j = r + 2;
+        if (y >= pl.H) break;
+        const uint64_t d = D[i];
+        // erosion: out-of-image neighbours count as set
+        const uint64_t dl = k > 0 ? ((L[j] >> 63) | (L[j] >> 62) | C[j] | (L[j - 1] >> 63) | (L[j + 1] >> 63)) & 1ull : 1ull;
+        uint64_t dr = 0;                                           // right neighbour of the last column is outside
+        if (valid > 64) dr = ((R[j] | (R[j] >> 1) | (C[j] >> 63) | R[j - 1] | R[j + 1]) & 1ull) << 63;
+        uint64_t right = (d >> 1) | dr;
+        if (valid <= 64) right |= 1ull << (valid - 1);             // pixel W-1 looks right at "outside" = set
+        const uint64_t leftn = (d << 1) | dl;
+        const uint64_t upn = y > 0 ? D[i - 1] : ~0ull;
+        const uint64_t dnn = y + 1 < pl.H ? D[i + 1] : ~0ull;
+        op[(size_t)y * pl.wpr + k] = d & leftn & right & upn & dnn & vmask;
+    }
 }
 
 // flatten + per-root area (aux0) and brightness sum (aux1)
@@ -567,7 +585,7 @@ extern "C" int ipx_cluster_stats(ipx_ctx *ctx, const uint8_t *frames, const uint
         const uint8_t *kp = keep ? keep + first : nullptr;
         const size_t nw = pl.words * nb;
         const dim3 grid((unsigned)((nw + 255) / 256)), block(256);
-        IPX_LAUNCH(ctx, KID_CLOSE, nw * 16, close_cross3_kernel, grid, block, mb, pl, nb, kp, closed);
+        IPX_LAUNCH(ctx, KID_CLOSE, nw * 16, close_cross3_kernel, dim3((pl.wpr + 31) / 32, (pl.H + 8 * CC_RB - 1) / (8 * CC_RB), nb), dim3(256), mb, pl, nb, kp, closed);
         IPX_LAUNCH(ctx, KID_CCL_INIT, nw * 8, ccl_init_kernel, grid, block, closed, pl, nb, par, aux0, aux1);
         IPX_LAUNCH(ctx, KID_CCL_MERGE, nw * 8, ccl_merge_kernel, grid, block, closed, pl, nb, par);
         IPX_LAUNCH(ctx, KID_CCL_REDUCE, nw * 8, cluster_accum_kernel, grid, block, closed, fr, pl, nb, par, aux0, aux1);
