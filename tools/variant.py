@@ -3,6 +3,7 @@
 
   python tools/variant.py <name> [-DMACRO=value ...]   here (CPU): image_processing_amd/lib_<name>/libipx.so,
                                                        flow.hip and flow_iter.hip compiled with the extra flags
+  VARIANT_SRCS=ccl.hip,detect.hip python tools/variant.py ...   other translation units instead
 """
 import os
 import subprocess
@@ -18,7 +19,7 @@ def main():
     b.build_lib()
     d = os.path.join(ROOT, "image_processing_amd", "lib_" + name)
     os.makedirs(d, exist_ok=True)
-    mine = ["flow.hip", "flow_iter.hip"]
+    mine = os.environ.get("VARIANT_SRCS", "flow.hip,flow_iter.hip").split(",")
     procs = [subprocess.Popen([b._hipcc()] + b.FLAGS + b.EXTRA_FLAGS.get(s, []) + extra +
                               ["-c", os.path.join(b.CSRC, s), "-o", os.path.join(d, s.replace(".hip", ".o"))]) for s in mine]
     if any(p.wait() != 0 for p in procs):
