@@ -45,7 +45,8 @@ def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--warmup", type=int, default=2,
+                    help="untimed steps first (default 2: the loop is pipelined over two chunks and two result slots, and the first step of each still sets buffers up: tools/step_times.py)")
     ap.add_argument("--frames", type=int, default=None, help="frames per GPU per step (default 1000)")
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--width", type=int, default=1920)
