@@ -170,6 +170,11 @@ __device__ __forceinline__ void um_finish(const UmIn &in, float2 d, int x, int y
 // banks (the two-way conflicts are 15 % of the LDS cycles and cost nothing); deeper prefetch, 64-column strips,
 // one output per thread in C, and 1024-thread workgroups whose two halves take consecutive pairs in lockstep so
 // that the shared expansion is fetched once per CU (the coupled barrier costs more than the saved misses return).
+// Later in round 2 (final build: ~4.05k cycles per step, vector ALUs 81 % busy at 1.91 GHz, DESIGN.md sections 3 and 9): the flow
+// field moved non-temporally (-1 %); the short reciprocal in the solve (-0.7 %); and three probes that locate the limit -- 16 vector
+// instructions per step fewer in the producers: +-0; the fifth channel of phase B moved to two producer waves: +4.5 %; the same
+// short form for the two sqrtf of the magnitude sum: -0.15 %.  Both roles are as long as the step, the producers paced by the
+// bytes they pull through L1, the consumers by the length of their dependent chains.
 struct FiVec {                  // a flow vector in flight: IN 0 uses p00 only
     float2 p00, p01, p10, p11;
     float b1;
