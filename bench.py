@@ -6,9 +6,14 @@
 A step = one pass of the whole path (ipx_detect_chunk's stages, ip.py:526-632) over one chunk of
 synthetic 1920x1080 uint8 frames already resident in HBM, results copied back and turned into the
 reference's four float64 arrays.  N = 1: BASELINE.json configs[1] ("1 MI355X, 1920x1080 synthetic
-video", processed in the reference's 1000-frame chunks).  N > 1 (launched by torch.distributed.run,
-one rank per GPU): configs[2], a chunk of N x 1000 frames is sharded by frame range, 1000 frames per GPU
-(weak scaling), with the persistence / static-map / result exchanges over RCCL inside the step.
+video", processed in the reference's 1000-frame chunks).  N > 1 (one rank per GPU): configs[2], a chunk of
+N x 1000 frames is sharded by frame range, 1000 frames per GPU (weak scaling), with the persistence /
+static-map / result exchanges over RCCL inside the step.
+
+Launching N > 1.  Under a launcher (`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`:
+WORLD_SIZE is set) this process IS a rank.  Started plainly (`python bench.py --gpus N`, no WORLD_SIZE) it starts
+that launcher itself as a fresh child process -- before this process has imported torch or touched the GPU --
+relays rank 0's JSON line and exits with the child's status.
 
 Rank 0 prints ONE JSON line.
 * `value`: K steps timed with the built-in profiler OFF.
@@ -21,7 +26,9 @@ Rank 0 prints ONE JSON line.
 * `throughput_pinned_host`, `throughput_from_avi` (N = 1, never `value`): the same path with chunks starting in
   pinned host memory (upload on a side stream under the previous chunk) and in an uncompressed AVI on disk
   (decode thread + the above), SURVEY section 8(d) figures (ii) and (iii).  --no-modes skips them.
-* N > 1: `collectives`: GPU milliseconds, calls and bytes of the RCCL exchanges per chunk.
+* N > 1: `collectives`: GPU milliseconds, calls and bytes of the RCCL exchanges per chunk; `strong_1000`: the
+  reference's own 1000-frame chunk (ip.py:1186-1192) split N ways, 1000 / N frames per GPU (strong scaling;
+  what a drop-in user's single video gets from N GPUs through intra-chunk sharding), same timing rules.
 
 Other workloads (never the default): --height/--width/--frames, --motion (configs[3]), and
 --videos V (configs[4]): V synthetic videos of --video-frames frames in uncompressed AVI files, every rank (= GPU
@@ -55,6 +62,8 @@ def parse():
     ap.add_argument("--no-profile", action="store_true", help="skip the profiled pass (roofline = null)")
     ap.add_argument("--profile-steps", type=int, default=2, help="steps of the profiled pass")
     ap.add_argument("--no-modes", action="store_true", help="skip the pinned-host and from-AVI throughput figures")
+    ap.add_argument("--strong-frames", type=int, default=1000,
+                    help="N > 1: frames of the chunk that is also timed split N ways (strong scaling; 0 = skip)")
     ap.add_argument("--videos", type=int, default=0, help="configs[4]: number of videos of the multi-video batch")
     ap.add_argument("--video-frames", type=int, default=240, help="frames per video (--videos)")
     ap.add_argument("--video-chunk", type=int, default=120, help="step_size of the chunk driver (--videos)")
@@ -243,8 +252,36 @@ def bench_videos(args, world, rank, dev):
         print(json.dumps(line))
 
 
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher: run the N ranks under torch.distributed.run in a child process
+    (this process has not imported torch, so nothing here holds GPU state), relay the JSON line, return its status."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    p = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, env=env)
+    line = None
+    for ln in p.stdout:
+        t = ln.strip()
+        if t.startswith("{") and t.endswith("}"):
+            line = t                                   # rank 0's result (the last such line wins)
+        else:
+            sys.stderr.write(ln)                       # anything else a rank printed
+    rc = p.wait()
+    if line is not None:
+        print(line, flush=True)
+    return rc if rc != 0 else (0 if line is not None else 1)
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -280,35 +317,42 @@ def main():
     eng = Engine(local_rank)
     comm = sharding.make_comm()
     radius = int(eng.params.sliding_window_radius)
-
-    # ---- synthetic chunks in HBM (two distinct ones, alternated) ---------------------------------
     speeds = [0, 0.5, 4, 8] if args.motion else None
-    a, b = sharding.shard_range(n_total, rank, world)
-    lo, hi = sharding.halo_range(n_total, a, b, radius)
-    chunks = []
-    for c in range(2):
-        own = synth.chunk_torch(1000 * c + 2 + rank, b - a, H, W, dev, speeds=speeds)
-        if world > 1:   # halo frames come from the neighbours' ranges (stands in for decoding them)
-            r = max(radius, 1)
-            edges = comm.all_gather(torch.cat([own[:r], own[-r:]]).contiguous())
-            parts = []
-            if rank > 0:
-                parts.append(edges[rank - 1][r:][-(a - lo):])
-            parts.append(own)
-            if rank + 1 < world:
-                parts.append(edges[rank + 1][:r][:hi - b])
-            own = torch.cat(parts).contiguous()
-        chunks.append(own)
 
-    def submit(i):
-        """Enqueue step i; returns a callable that completes it (copy-back + the host's float glue)."""
-        fr = chunks[i % 2]
-        if world == 1:
-            return eng.detect_chunk_async(fr).result
-        out = sharding.detect_chunk_sharded(eng, fr, a, b, n_total, comm)
-        return lambda: sharding.results_to_host(out, H * W)
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
 
-    def run(first, count):
+    def make_job(n_frames):
+        """Two distinct synthetic chunks of `n_frames` frames in HBM, this rank's frame range + halo of each, and
+        submit(i): enqueue step i, return a callable that completes it (copy-back + the host's float glue)."""
+        a, b = sharding.shard_range(n_frames, rank, world)
+        lo, hi = sharding.halo_range(n_frames, a, b, radius)
+        chunks = []
+        for c in range(2):
+            own = synth.chunk_torch(1000 * c + 2 + rank, b - a, H, W, dev, speeds=speeds)
+            if world > 1:   # halo frames come from the neighbours' ranges (stands in for decoding them)
+                r = max(radius, 1)
+                edges = comm.all_gather(torch.cat([own[:r], own[-r:]]).contiguous())
+                parts = []
+                if rank > 0:
+                    parts.append(edges[rank - 1][r:][-(a - lo):])
+                parts.append(own)
+                if rank + 1 < world:
+                    parts.append(edges[rank + 1][:r][:hi - b])
+                own = torch.cat(parts).contiguous()
+            chunks.append(own)
+
+        def submit(i):
+            fr = chunks[i % 2]
+            if world == 1:
+                return eng.detect_chunk_async(fr).result
+            out = sharding.detect_chunk_sharded(eng, fr, a, b, n_frames, comm)
+            return lambda: sharding.results_to_host(out, H * W)
+        return chunks, submit
+
+    def run(submit, first, count):
         """`count` steps, software-pipelined as a chunk driver would: step k+1 is on the GPU while the host
         finishes step k.  Every step's results are produced inside the call."""
         res, pending = [], None
@@ -321,22 +365,23 @@ def main():
             res.append(pending())
         return res
 
-    def fence():
+    def timed(submit):
+        """W untimed steps, then K steps between fences; the slowest rank's time."""
+        run(submit, 0, args.warmup)
+        fence()
+        t0 = time.perf_counter()
+        res = run(submit, args.warmup, args.steps)
+        fence()
+        dt = time.perf_counter() - t0
         if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
+            t = torch.tensor([dt], dtype=torch.float64, device="cpu" if rehearse else dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return res, dt
 
     # ---- pass 1: the timed steps, profiler off ------------------------------------------------------
-    run(0, args.warmup)
-    fence()
-    t0 = time.perf_counter()
-    results = run(args.warmup, args.steps)
-    fence()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cpu" if rehearse else dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    chunks, submit = make_job(n_total)
+    results, dt = timed(submit)
 
     # ---- pass 2: the same steps with per-kernel events (roofline, kernel table, collective times) -----
     prof, coll, psteps, dt_prof = {}, None, max(1, args.profile_steps), None
@@ -348,7 +393,7 @@ def main():
             comm.timed = True
         fence()
         t1 = time.perf_counter()
-        run(args.warmup, psteps)
+        run(submit, args.warmup, psteps)
         fence()
         dt_prof = time.perf_counter() - t1
         prof = eng.profile_read()
@@ -359,6 +404,18 @@ def main():
             comm.timed = False
             coll = dict(ms_per_chunk=round(ms / psteps, 3), calls_per_chunk=calls // psteps, bytes_per_chunk=nbytes // psteps,
                         backend="gloo (rehearsal)" if rehearse else "nccl (RCCL)", rank=0)
+
+    # ---- N > 1: the reference's 1000-frame chunk split N ways (strong scaling) ------------------------
+    strong = None
+    S = args.strong_frames
+    if world > 1 and S > 0 and S // world >= max(2, int(eng.params.consecutive_threshold)):
+        chunks_s, submit_s = make_job(S)
+        res_s, dt_s = timed(submit_s)
+        strong = dict(value=round(S * args.steps / dt_s, 2), unit="frames/s", ms_per_step=round(1e3 * dt_s / args.steps, 3),
+                      scaling="strong", frames_per_chunk=S, frames_per_gpu=S // world,
+                      what="one %d-frame chunk (the reference's step_size, ip.py:1186-1192) sharded by frame range "
+                           "over %d GPUs" % (S, world))
+        del chunks_s, submit_s, res_s
 
     if rank == 0:
         copy_gbs = device_copy_gbs(chunks[0])
@@ -404,6 +461,8 @@ def main():
                     roofline=roof, cpu_baseline=cpu, kernels=kernels)
         if coll:
             line["collectives"] = coll
+        if strong:
+            line["strong_1000"] = strong
         if world == 1 and not args.no_modes:
             try:
                 line["throughput_pinned_host"], line["throughput_from_avi"] = throughput_modes(chunks, H, W)

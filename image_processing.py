@@ -843,9 +843,85 @@ def _checkpoint_fingerprint(video_filename, num_frames, step_size, params):
                            ipx_version=int(_ipx.lib.ipx_version())), sort_keys=True, default=float)
 
 
+def _resolve_devices(gpus):
+    """``gpus`` of main() -> list of device ordinals, or None for "this thread's current device".
+    None reads the environment variable IPX_GPUS (a count or a comma-separated list of ordinals); a count N means
+    devices 0 .. N-1; a list may name a device more than once (two pipelines on one GPU: how a one-GPU box rehearses it)."""
+    if gpus is None:
+        env = os.environ.get("IPX_GPUS", "").strip()
+        if not env:
+            return None
+        gpus = [int(x) for x in env.split(",") if x.strip()] if "," in env else int(env)
+    if isinstance(gpus, (int, np.integer)) and not isinstance(gpus, bool):
+        n = int(gpus)
+        if n < 1:
+            raise ValueError("gpus must be at least 1")
+        import torch
+        if n > torch.cuda.device_count():
+            raise ValueError("gpus=%d but this node shows %d GPU(s)" % (n, torch.cuda.device_count()))
+        return list(range(n)) if n > 1 else None
+    devs = [int(d) for d in gpus]
+    if not devs:
+        raise ValueError("gpus: empty device list")
+    return devs
+
+
+def _chunk_pipeline(video_filename, spans, order, kw, deliver, announce):
+    """The double-buffered chunk loop on the calling thread's current device: a second thread decodes the next
+    chunk of ``order`` (indices into ``spans``) into pinned memory while the current one is on the GPU, and a chunk
+    is enqueued before the host turns the previous one's integers into the float series.  ``deliver(idx, res)`` gets
+    every finished chunk; ``announce(idx)`` is called when a chunk is taken up."""
+    if not order:
+        return
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max_workers=1) as decoder:
+        nxt = decoder.submit(_load_chunk, video_filename, *spans[order[0]])
+        pending = None                                   # (completion, idx) of the chunk on the GPU
+        for k, idx in enumerate(order):
+            chunk = nxt.result()
+            if k + 1 < len(order):
+                nxt = decoder.submit(_load_chunk, video_filename, *spans[order[k + 1]])
+            announce(idx)
+            done = _submit_chunk(chunk, idx, kw)
+            if pending is not None:
+                deliver(pending[1], pending[0]())
+            pending = (done, idx)
+        if pending is not None:
+            deliver(pending[1], pending[0]())
+
+
+def _chunks_on_group(video_filename, spans, order, kw, devices, deliver, announce):
+    """Fewer chunks than GPUs: every chunk is sharded by frame range over all ``devices`` inside libipx
+    (ipx_group_detect_chunk: one host thread, context and stream per device, halo frames uploaded with each range,
+    persistence / static-map exchanges over RCCL or peer copies) instead of leaving GPUs idle."""
+    from concurrent.futures import ThreadPoolExecutor
+    from image_processing_amd.engine import Group
+    settings = _prepare_settings(kw["params"])
+    group = Group(devices, params=_engine_params(settings))
+    try:
+        with ThreadPoolExecutor(max_workers=1) as decoder:
+            nxt = decoder.submit(_load_chunk, video_filename, *spans[order[0]])
+            for k, idx in enumerate(order):
+                frames, pinned = nxt.result()
+                if k + 1 < len(order):
+                    nxt = decoder.submit(_load_chunk, video_filename, *spans[order[k + 1]])
+                announce(idx)
+                host = pinned.numpy() if pinned is not None else _as_u8(np.stack([np.asarray(f) for f in frames]))
+                T = max(int(settings.consecutive_threshold) - 1, 1)
+                if len(host) < len(devices) * max(T, 2):         # too short to cut: one device, the ordinary way
+                    import torch
+                    with torch.cuda.device(devices[0]):
+                        deliver(idx, _submit_chunk((frames, pinned), idx, kw)())
+                    continue
+                r = group.detect_chunk(host)
+                deliver(idx, (r["total_counts"], r["cluster_counts"], r["avg_sizes"], r["avg_brightnesses"]))
+    finally:
+        group.close()
+
+
 def main(video_filename, average_time=1.0, max_chunks=None, step_size=1000, plot=False, show_plots=False,
          save_plots=False, output_folder="results", visualise_damaged_pixels_plot=True, plot_damaged_pixels_plot=True,
-         plot_heatmap_plot=True, params=None, *, checkpoint_folder=None):
+         plot_heatmap_plot=True, params=None, *, checkpoint_folder=None, gpus=None):
     """ip.py:1136-1247: process a video in chunks of ``step_size`` frames and return the per-window
     averages (``average_time`` seconds each) of the four per-frame series, plus the window mid-times.
 
@@ -853,14 +929,21 @@ def main(video_filename, average_time=1.0, max_chunks=None, step_size=1000, plot
     chunk's four series are written to ``chunk_<start>_<end>.npz`` there together with a fingerprint of the
     video file, the chunking, the settings and the library version; a chunk whose file exists AND carries this
     run's fingerprint is neither decoded nor processed again (resume after an interruption; no plots for such
-    chunks); any other file of that name is recomputed and overwritten."""
+    chunks); any other file of that name is recomputed and overwritten.
+
+    ``gpus`` (not in the reference, which is one process on CPU cores): a count or a list of device ordinals;
+    default: the environment variable IPX_GPUS, else the calling thread's current device only.  Chunks are
+    independent of each other (ip.py:1204-1227: each is loaded and processed on its own), so chunk k goes to device
+    k mod N, every device with its own decode thread, libipx context and upload stream; when fewer chunks than
+    devices are left to do, each chunk is sharded by frame range over all devices instead (ipx_group_detect_chunk).
+    The results are those of a single-device run, bit for bit.  A run that plots, or in which a stage of this module
+    has been replaced, stays on one device (those paths run stage by stage on the calling thread)."""
     num_frames, FPS = _video_info(video_filename)
     edges = np.arange(0, num_frames, step_size)
     if edges[-1] != num_frames:
         edges = np.concatenate([edges, [num_frames]])
     if max_chunks is not None:
         edges = edges[:max_chunks + 1]
-    per_chunk = ([], [], [], [])
     step = int(round(FPS * average_time))
     spans = [(int(edges[i]), int(edges[i + 1])) for i in range(len(edges) - 1)]
     kw = dict(plot=plot, show_plots=show_plots, save_plots=save_plots, output_folder=output_folder,
@@ -886,45 +969,51 @@ def main(video_filename, average_time=1.0, max_chunks=None, step_size=1000, plot
         except Exception:                               # noqa: BLE001 - truncated / foreign file: recompute, overwrite
             return None
 
-    def collect(res, span=None):
-        for store, series in zip(per_chunk, res):
-            store.append(series)
-        path = ckpt_path(span) if span else None
-        if path:                                        # computed in this run: (over)write
-            os.makedirs(checkpoint_folder, exist_ok=True)
+    results = [from_checkpoint(sp) for sp in spans]     # per chunk: the four series
+    todo = [i for i in range(len(spans)) if results[i] is None]
+    for i, r in enumerate(results):
+        if r is not None:
+            print(f"chunk {i}: frames {spans[i][0]}–{spans[i][1]} taken from {ckpt_path(spans[i])}")
+    lock = _threading.Lock()
+
+    def deliver(idx, res):
+        """A chunk computed in this run: keep it and (over)write its checkpoint."""
+        results[idx] = tuple(res)
+        path = ckpt_path(spans[idx])
+        if path:
+            with lock:
+                os.makedirs(checkpoint_folder, exist_ok=True)
             tmp = path + ".tmp.npz"
             np.savez(tmp, total_counts=res[0], cluster_counts=res[1], avg_sizes=res[2], avg_brightnesses=res[3],
-                     n_frames=span[1] - span[0], fingerprint=fingerprint)
+                     n_frames=spans[idx][1] - spans[idx][0], fingerprint=fingerprint)
             os.replace(tmp, path)
 
-    # Double-buffered streaming: a second thread decodes chunk k+1 (into pinned memory) while chunk k is on
-    # the GPU, and chunk k+1 is enqueued before the host turns chunk k's integers into the float series.
-    from concurrent.futures import ThreadPoolExecutor
-    saved = [from_checkpoint(sp) for sp in spans]
-    todo = [i for i in range(len(spans)) if saved[i] is None]
-    with ThreadPoolExecutor(max_workers=1) as decoder:
-        nxt = decoder.submit(_load_chunk, video_filename, *spans[todo[0]]) if todo else None
-        pending = None                                   # (completion, span) of the chunk on the GPU
-        for idx, (start, end) in enumerate(spans):
-            if saved[idx] is not None:
-                if pending is not None:                  # keep the series in chunk order
-                    collect(pending[0](), pending[1])
-                    pending = None
-                print(f"chunk {idx}: frames {start}–{end} taken from {ckpt_path(spans[idx])}")
-                collect(saved[idx])
-                continue
-            chunk = nxt.result()
-            later = [i for i in todo if i > idx]
-            if later:
-                nxt = decoder.submit(_load_chunk, video_filename, *spans[later[0]])
-            print(f"processing chunk {idx}: frames {start}–{end}")
-            done = _submit_chunk(chunk, idx, kw)
-            if pending is not None:
-                collect(pending[0](), pending[1])
-            pending = (done, spans[idx])
-        if pending is not None:
-            collect(pending[0](), pending[1])
-    counts, clusters, sizes, brightness = (np.concatenate(s) for s in per_chunk)
+    def announce(idx):
+        print(f"processing chunk {idx}: frames {spans[idx][0]}–{spans[idx][1]}")
+
+    devices = _resolve_devices(gpus)
+    if devices is not None and len(devices) > 1 and (plot or not _pristine(*_STAGES) or
+                                                     not _pristine("detect_damaged_pixels", "load_video_frames")):
+        devices = devices[:1]
+    if devices is None:
+        _chunk_pipeline(video_filename, spans, todo, kw, deliver, announce)
+    elif len(devices) == 1:
+        import torch
+        with torch.cuda.device(devices[0]):
+            _chunk_pipeline(video_filename, spans, todo, kw, deliver, announce)
+    elif todo and len(todo) < len(devices):
+        _chunks_on_group(video_filename, spans, todo, kw, devices, deliver, announce)
+    elif todo:
+        from concurrent.futures import ThreadPoolExecutor
+        import torch
+
+        def on_device(slot):
+            torch.cuda.set_device(devices[slot])         # the device of THIS thread; its libipx context is thread-local
+            _chunk_pipeline(video_filename, spans, todo[slot::len(devices)], kw, deliver, announce)
+        with ThreadPoolExecutor(max_workers=len(devices)) as pool:
+            for f in [pool.submit(on_device, s) for s in range(len(devices))]:
+                f.result()
+    counts, clusters, sizes, brightness = (np.concatenate([r[k] for r in results]) for k in range(4))
     averages_counts = chunked_nanmean(counts, step)
     times = ((np.arange(len(averages_counts)) * step) + step / 2) / FPS
     return {
@@ -960,6 +1049,7 @@ def _cli_options(argv=None):
     parser.add_argument("-cp", "--chunk_plots", help="(Default=True) True or False: per-chunk plots")
     parser.add_argument("-ap", "--average_plots", help="(Default=True) True or False: final averages plot")
     parser.add_argument("-of", "--output_folder", help="Location of where saved plots are saved")
+    parser.add_argument("-gp", "--gpus", help="(not in the reference) number of GPUs or comma-separated device ordinals; chunks are dealt over them")
     parser.add_argument("-ckf", "--checkpoint_folder", help="(not in the reference) per-chunk .npz results; finished chunks are skipped on a rerun")
     for short, name in (("-ct", "consecutive_threshold"), ("-bt", "brightness_threshold"), ("-ft", "flow_threshold"),
                         ("-st", "static_threshold"), ("-mncs", "min_cluster_size"), ("-mxcs", "max_cluster_size"),
@@ -998,7 +1088,8 @@ def _cli_options(argv=None):
         visualise_damaged_pixels_plot=flag(args.visualise_damaged_pixels_plot, False),
         plot_damaged_pixels_plot=flag(args.plot_damaged_pixels_plot, True),
         plot_heatmap_plot=flag(args.plot_heatmap_plot, True), params=params,
-        checkpoint_folder=args.checkpoint_folder or None)
+        checkpoint_folder=args.checkpoint_folder or None,
+        gpus=([int(x) for x in args.gpus.split(",")] if "," in args.gpus else int(args.gpus)) if args.gpus else None)
     return dict(video_filename=args.video_filename if args.video_filename else "11_01_H_170726081325.avi",
                 main_kwargs=main_kwargs, show_plots=show_plots, save_plots=save_plots,
                 average_plots=flag(args.average_plots, True))

@@ -166,6 +166,7 @@ def _cli(argv=None):
         sys.path.insert(0, root)
     import image_processing as ip
     opts = ip._cli_options(rest)                        # the reference's flags (ip.py:1250-1316), video_filename unused
+    opts["main_kwargs"].pop("gpus", None)               # here --gpus counts worker processes; every worker drives one device
     videos = [v for v in args.videos.split(",") if v]
     devices = [int(d) for d in args.devices.split(",")] if args.devices else None
     t0 = time.perf_counter()
