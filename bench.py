@@ -64,6 +64,10 @@ def parse():
     ap.add_argument("--no-modes", action="store_true", help="skip the pinned-host and from-AVI throughput figures")
     ap.add_argument("--strong-frames", type=int, default=1000,
                     help="N > 1: frames of the chunk that is also timed split N ways (strong scaling; 0 = skip)")
+    ap.add_argument("--group", type=int, default=0,
+                    help="one process, N ranks inside libipx (ipx_group_submit / ipx_group_wait): chunks start in pinned host memory")
+    ap.add_argument("--group-devices", default=None, help="comma-separated device ordinals of the ranks (default: 0..N-1, or N times device 0 on a smaller node)")
+    ap.add_argument("--group-transport", default="auto", choices=["auto", "peer", "rccl"])
     ap.add_argument("--videos", type=int, default=0, help="configs[4]: number of videos of the multi-video batch")
     ap.add_argument("--video-frames", type=int, default=240, help="frames per video (--videos)")
     ap.add_argument("--video-chunk", type=int, default=120, help="step_size of the chunk driver (--videos)")
@@ -278,8 +282,70 @@ def self_launch(args):
     return rc if rc != 0 else (0 if line is not None else 1)
 
 
+def bench_group(args):
+    """--group N: the in-library multi-GPU path as a single-process caller (a C program, the reference's own module) sees it:
+    one chunk of --frames frames in PINNED HOST memory per step, cut by frame range over N ranks inside libipx, two chunks
+    in flight (chunk k+1 uploads under chunk k).  The figure includes the PCIe upload: never `value` of the default run."""
+    import numpy as np
+    import torch
+    from image_processing_amd import hostmath, synth
+    from image_processing_amd.engine import Group
+    N = args.group
+    have = torch.cuda.device_count()
+    if args.group_devices:
+        devices = [int(x) for x in args.group_devices.split(",")]
+    else:
+        devices = list(range(N)) if have >= N else [0] * N
+    H, W, n = args.height, args.width, args.frames or 1000
+    dev0 = torch.device("cuda", devices[0])
+    speeds = [0, 0.5, 4, 8] if args.motion else None
+    pinned = []
+    for c in range(2):
+        fr = synth.chunk_torch(1000 * c + 2, n, H, W, dev0, speeds=speeds)
+        p = torch.empty(fr.shape, dtype=torch.uint8, pin_memory=True)
+        p.copy_(fr)
+        pinned.append(p)
+        del fr
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
+    g = Group(devices, transport=args.group_transport)
+
+    def run(first, count):
+        res, pend = [], None
+        for i in range(first, first + count):
+            h = g.submit(pinned[i % 2].numpy())        # the upload starts at once, under the chunk before
+            if pend is not None:
+                res.append(g.wait(pend))
+            pend = h
+        if pend is not None:
+            res.append(g.wait(pend))
+        return res
+
+    run(0, args.warmup)
+    t0 = time.perf_counter()
+    results = run(args.warmup, args.steps)
+    dt = time.perf_counter() - t0
+    thr = float(g.params.flow_threshold)
+    margins = [hostmath.flow_margin(r["flows"], thr) for r in results]
+    line = dict(metric="frames/sec (whole node) at 1080p, from pinned host memory through ipx_group_*",
+                value=round(n * args.steps / dt, 2), unit="frames/s", n_gpus=len(set(devices)), ranks=N, steps=args.steps,
+                warmup=args.warmup, ms_per_step=round(1e3 * dt / args.steps, 3), higher_is_better=True, scaling="strong",
+                vs_baseline=None, dtype="u8 (flow metric in f32/f64)", data="synthetic",
+                config=dict(workload="%dx%d u8, %d-frame chunks in pinned host memory, cut by frame range over %d ranks inside "
+                                     "libipx (devices %s, transport %s), two chunks in flight" % (W, H, n, N, devices, g.transport),
+                            frames_per_rank=n // N, upload_gbs=round(n * H * W * args.steps / dt / 1e9, 2),
+                            kept_frames_last_step=int(np.sum(results[-1]["keep"])),
+                            min_flow_margin=round(min(m["min_margin"] for m in margins), 6)),
+                roofline=None, cpu_baseline=None,
+                note="includes the PCIe upload of every frame: not roofline-comparable; the resident figure is the default run's `value`")
+    g.close()
+    print(json.dumps(line))
+
+
 def main():
     args = parse()
+    if args.group > 0:
+        return bench_group(args)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(args))
     import numpy as np

@@ -744,12 +744,114 @@ def _video_info(video_filename):
 _DECODE_THREADS = 8
 
 
+class _RawChunk:
+    """A chunk still in the layout the AVI file stores it in: the bytes of frames [start, end) -- DIBs, bottom-up rows
+    padded to 4 bytes, 8 bytes of chunk header between consecutive frames -- read with a few large positional reads into
+    a pinned staging buffer.  The row flip, the padding and (24-bit streams) the luma conversion are left to the GPU
+    (ipx_unpack_dib), so the decode thread moves every byte exactly once, at memcpy speed."""
+
+    def __init__(self, slot, nbytes, n, rec, height, width, bpp, stride, bottom_up):
+        self.slot, self.nbytes, self.n, self.rec = slot, nbytes, n, rec
+        self.height, self.width, self.bpp, self.stride, self.bottom_up = height, width, bpp, stride, bottom_up
+
+    def __len__(self):
+        return self.n
+
+    def frames(self):
+        """The frames as load_video_frames returns them (only a stage-by-stage run needs them on the host)."""
+        raw = self.slot["host"].numpy()[:self.nbytes]
+        out = []
+        for i in range(self.n):
+            a = raw[i * self.rec:i * self.rec + self.stride * self.height].reshape(self.height, self.stride)
+            a = a[::-1] if self.bottom_up else a
+            if self.bpp == 8:
+                out.append(np.ascontiguousarray(a[:, :self.width]))
+            else:
+                out.append(_to_grey(np.ascontiguousarray(a[:, :3 * self.width].reshape(self.height, self.width, 3))))
+        return out
+
+
+class _StagingRing:
+    """Three pinned staging buffers of one chunk driver: one being read into by its decode thread, one uploading, one
+    spare -- so the decode of chunk k+2 can start while chunk k+1 uploads.  Buffers are pinned once and reused for every
+    later chunk (pinning 2 GB of fresh memory per chunk was two thirds of a first pass's time); a driver returns its
+    ring to the pool when it is done, and the next video's driver takes it over."""
+    SLOTS = 3
+
+    def __init__(self):
+        self.slots, self.next = [], 0
+
+    def take(self, nbytes):
+        """The next buffer, at least ``nbytes`` long and no longer read by an upload (waits for that upload if need be)."""
+        import torch
+        if len(self.slots) < self.SLOTS:
+            self.slots.append(dict(host=None, busy=None))
+            slot = self.slots[-1]
+        else:
+            slot = self.slots[self.next % self.SLOTS]
+        self.next += 1
+        if slot["busy"] is not None:
+            slot["busy"].synchronize()
+            slot["busy"] = None
+        if slot["host"] is None or slot["host"].numel() < nbytes:
+            slot["host"] = None                           # (released before the larger one is pinned)
+            slot["host"] = torch.empty(int(nbytes + (nbytes >> 4)), dtype=torch.uint8, pin_memory=True)
+        return slot
+
+
+_RING_POOL = []
+_RING_LOCK = _threading.Lock()
+
+
+def _ring_acquire():
+    with _RING_LOCK:
+        return _RING_POOL.pop() if _RING_POOL else _StagingRing()
+
+
+def _ring_release(ring):
+    for slot in ring.slots:                               # nothing may still be reading the buffers when the next driver writes them
+        if slot["busy"] is not None:
+            slot["busy"].synchronize()
+            slot["busy"] = None
+    with _RING_LOCK:
+        if len(_RING_POOL) < 16:
+            _RING_POOL.append(ring)
+
+
+def _load_chunk_raw_avi(video_filename, start, end, ring):
+    """The decode thread's short cut for uncompressed AVI files (what the benchmarks and the camera pipeline store) read
+    by our own reader, with load_video_frames not replaced by the caller: the chunk's bytes go from the page cache into
+    pinned memory as they are stored.  Returns None when any of that does not hold (cv2 importable, compressed or
+    palettised-colour stream, frames not evenly spaced in the file)."""
+    if ring is None or cv2 is not None or not _pristine("load_video_frames"):
+        return None
+    try:
+        import torch
+        if not torch.cuda.is_available():
+            return None
+        reader = _avi.AviReader(video_filename)
+    except (OSError, ValueError, ImportError):
+        return None
+    try:
+        if reader.bpp == 8 and not reader.grey_palette:   # indices that are not grey levels: the general path
+            return None
+        start, end = int(start or 0), min(int(end), reader.frame_count) if end else reader.frame_count
+        layout = reader.record_layout(start, end)
+        if layout is None:
+            return None
+        off0, rec, nbytes = layout
+        slot = ring.take(nbytes)
+        reader.read_region_into(off0, slot["host"].numpy()[:nbytes], threads=_DECODE_THREADS)
+        return _RawChunk(slot, nbytes, end - start, rec, reader.height, reader.width, reader.bpp, reader.stride,
+                         reader.bottom_up)
+    finally:
+        reader.close()
+
+
 def _load_chunk_gray_avi(video_filename, start, end):
-    """The decode thread's short cut for what the benchmarks and the camera pipeline store: an uncompressed
-    8-bit AVI, read by our own reader (no cv2), with load_video_frames not replaced by the caller.  Frames go
-    from the page cache straight into one pinned buffer (a few copy threads; numpy releases the GIL), and the
-    list handed on holds views of it: the same frames load_video_frames returns, without the two extra
-    copies.  Returns None when any of that does not hold."""
+    """The same short cut one step less direct, for 8-bit AVI files whose frames are NOT evenly spaced (other chunks in
+    between): frame by frame from the mapping into one pinned buffer, rows turned over on the way (a few copy threads;
+    numpy releases the GIL).  The list handed on holds views of the buffer.  Returns None when it does not apply."""
     if cv2 is not None or not _pristine("load_video_frames"):
         return None
     try:
@@ -775,9 +877,14 @@ def _load_chunk_gray_avi(video_filename, start, end):
         reader.close()
 
 
-def _load_chunk(video_filename, start, end):
-    """Decode frames [start, end) through the module's load_video_frames; when they are plain greyscale
-    uint8 frames of one size they are also stacked into pinned host memory for the asynchronous upload."""
+def _load_chunk(video_filename, start, end, ring=None):
+    """Decode frames [start, end).  With a staging ring (the asynchronous chunk driver): a _RawChunk when the file allows
+    it.  Otherwise (frames, pinned): the frames through the module's load_video_frames -- or the 8-bit AVI short cut --
+    and, when they are plain greyscale uint8 frames of one size, the same frames stacked in pinned host memory for the
+    asynchronous upload."""
+    raw = _load_chunk_raw_avi(video_filename, start, end, ring)
+    if raw is not None:
+        return raw
     fast = _load_chunk_gray_avi(video_filename, start, end)
     if fast is not None:
         return fast
@@ -796,34 +903,45 @@ def _load_chunk(video_filename, start, end):
 
 
 def _submit_chunk(chunk, idx, kw):
-    """Start one chunk; returns a callable that yields detect_damaged_pixels' four arrays.  The asynchronous
-    path (pinned -> HBM on a side stream, ipx_detect_chunk enqueued, results copied back behind it) is taken
+    """Start one chunk; returns a callable that yields detect_damaged_pixels' four arrays (and, from the asynchronous
+    path, the chunk's flow metrics as a fifth: the chunk driver reports how close they came to the threshold).  The
+    asynchronous path (pinned -> HBM on a side stream, ipx_detect_chunk enqueued, results copied back behind it) is taken
     when nothing has to be plotted and no stage of this module has been replaced; otherwise the chunk goes
     through the module-global detect_damaged_pixels right here."""
-    frames, pinned = chunk
-    n = len(frames)
-    if pinned is None or n < 2 or kw["plot"] or not _pristine(*_STAGES) or not _pristine("detect_damaged_pixels"):
-        res = detect_damaged_pixels(frames, idx, **kw)
+    raw = chunk if isinstance(chunk, _RawChunk) else None
+    frames, pinned = (None, None) if raw is not None else chunk
+    n = len(raw) if raw is not None else len(frames)
+    can_async = (raw is not None or pinned is not None) and n >= 2 and not kw["plot"] and _pristine(*_STAGES) and \
+        _pristine("detect_damaged_pixels")
+    if not can_async:
+        res = detect_damaged_pixels(raw.frames() if raw is not None else frames, idx, **kw)
         return lambda: res
     import torch
     settings = _prepare_settings(kw["params"])
     with _Scoped(**_engine_params(settings)) as eng:
         copy_stream = getattr(_TLS, "copy_stream", None)
-        if copy_stream is None:
+        if copy_stream is None or copy_stream.device != eng.device:
             copy_stream = _TLS.copy_stream = torch.cuda.Stream(eng.device)
-        dev = torch.empty(pinned.shape, dtype=torch.uint8, device=eng.device)
+        src = raw.slot["host"][:raw.nbytes] if raw is not None else pinned
+        staged = torch.empty(src.shape, dtype=torch.uint8, device=eng.device)
         with torch.cuda.stream(copy_stream):
-            dev.copy_(pinned, non_blocking=True)
+            staged.copy_(src, non_blocking=True)
             uploaded = torch.cuda.Event()
             uploaded.record(copy_stream)
+        if raw is not None:
+            raw.slot["busy"] = uploaded                  # the ring hands this buffer out again only after the copy
         torch.cuda.current_stream(eng.device).wait_event(uploaded)
+        if raw is not None:                              # rows the right way up, padding dropped, colour -> grey: on the GPU
+            dev = eng.unpack_dib(staged, raw.rec, n, raw.height, raw.width, raw.bpp, raw.stride, raw.bottom_up)
+        else:
+            dev = staged
         handle = eng.detect_chunk_async(dev)
 
     def finish():
         r = handle.result()
-        del pinned_keepalive[:]
-        return r["total_counts"], r["cluster_counts"], r["avg_sizes"], r["avg_brightnesses"]
-    pinned_keepalive = [pinned, dev]
+        del keepalive[:]
+        return r["total_counts"], r["cluster_counts"], r["avg_sizes"], r["avg_brightnesses"], r["flows"]
+    keepalive = [pinned, staged, dev]
     return finish
 
 
@@ -874,20 +992,24 @@ def _chunk_pipeline(video_filename, spans, order, kw, deliver, announce):
     if not order:
         return
     from concurrent.futures import ThreadPoolExecutor
-    with ThreadPoolExecutor(max_workers=1) as decoder:
-        nxt = decoder.submit(_load_chunk, video_filename, *spans[order[0]])
-        pending = None                                   # (completion, idx) of the chunk on the GPU
-        for k, idx in enumerate(order):
-            chunk = nxt.result()
-            if k + 1 < len(order):
-                nxt = decoder.submit(_load_chunk, video_filename, *spans[order[k + 1]])
-            announce(idx)
-            done = _submit_chunk(chunk, idx, kw)
+    ring = _ring_acquire()
+    try:
+        with ThreadPoolExecutor(max_workers=1) as decoder:
+            nxt = decoder.submit(_load_chunk, video_filename, *spans[order[0]], ring)
+            pending = None                               # (completion, idx) of the chunk on the GPU
+            for k, idx in enumerate(order):
+                chunk = nxt.result()
+                if k + 1 < len(order):
+                    nxt = decoder.submit(_load_chunk, video_filename, *spans[order[k + 1]], ring)
+                announce(idx)
+                done = _submit_chunk(chunk, idx, kw)
+                if pending is not None:
+                    deliver(pending[1], pending[0]())
+                pending = (done, idx)
             if pending is not None:
                 deliver(pending[1], pending[0]())
-            pending = (done, idx)
-        if pending is not None:
-            deliver(pending[1], pending[0]())
+    finally:
+        _ring_release(ring)
 
 
 def _chunks_on_group(video_filename, spans, order, kw, devices, deliver, announce):
@@ -901,6 +1023,11 @@ def _chunks_on_group(video_filename, spans, order, kw, devices, deliver, announc
     try:
         with ThreadPoolExecutor(max_workers=1) as decoder:
             nxt = decoder.submit(_load_chunk, video_filename, *spans[order[0]])
+            pending = None                               # (idx, handle) of the chunk the ranks are computing
+
+            def finish():
+                r = group.wait(pending[1])
+                deliver(pending[0], (r["total_counts"], r["cluster_counts"], r["avg_sizes"], r["avg_brightnesses"], r["flows"]))
             for k, idx in enumerate(order):
                 frames, pinned = nxt.result()
                 if k + 1 < len(order):
@@ -909,12 +1036,20 @@ def _chunks_on_group(video_filename, spans, order, kw, devices, deliver, announc
                 host = pinned.numpy() if pinned is not None else _as_u8(np.stack([np.asarray(f) for f in frames]))
                 T = max(int(settings.consecutive_threshold) - 1, 1)
                 if len(host) < len(devices) * max(T, 2):         # too short to cut: one device, the ordinary way
+                    if pending is not None:
+                        finish()
+                        pending = None
                     import torch
                     with torch.cuda.device(devices[0]):
                         deliver(idx, _submit_chunk((frames, pinned), idx, kw)())
                     continue
-                r = group.detect_chunk(host)
-                deliver(idx, (r["total_counts"], r["cluster_counts"], r["avg_sizes"], r["avg_brightnesses"]))
+                handle = group.submit(host)              # its upload starts now, under the chunk before
+                handle["keepalive"] = pinned
+                if pending is not None:
+                    finish()
+                pending = (idx, handle)
+            if pending is not None:
+                finish()
     finally:
         group.close()
 
@@ -976,9 +1111,16 @@ def main(video_filename, average_time=1.0, max_chunks=None, step_size=1000, plot
             print(f"chunk {i}: frames {spans[i][0]}–{spans[i][1]} taken from {ckpt_path(spans[i])}")
     lock = _threading.Lock()
 
+    flow_threshold = float(_prepare_settings(params).flow_threshold)
+    margins = []                                         # per chunk computed here on the fused path: hostmath.flow_margin
+
     def deliver(idx, res):
         """A chunk computed in this run: keep it and (over)write its checkpoint."""
-        results[idx] = tuple(res)
+        if len(res) > 4:
+            with lock:
+                margins.append(_hostmath.flow_margin(res[4], flow_threshold, rel=1e-4))
+        res = tuple(res[:4])
+        results[idx] = res
         path = ckpt_path(spans[idx])
         if path:
             with lock:
@@ -1016,12 +1158,22 @@ def main(video_filename, average_time=1.0, max_chunks=None, step_size=1000, plot
     counts, clusters, sizes, brightness = (np.concatenate([r[k] for r in results]) for k in range(4))
     averages_counts = chunked_nanmean(counts, step)
     times = ((np.arange(len(averages_counts)) * step) + step / 2) / FPS
+    # The discard list (ip.py:559) is the one place where the float metric of the motion test decides an integer
+    # result, and the Farneback numerics behind it are restated from OpenCV's published algorithm, not pinned by a
+    # reference fixture: say so when a frame comes close enough to the threshold for the last bits to matter.
+    near = sum(m["frames_within_rel"] for m in margins)
+    if near:
+        print(f"warning: {near} frame(s) have a motion metric within 1e-4 (relative) of flow_threshold={flow_threshold}; "
+              f"whether they are kept depends on the last bits of the optical flow")
     return {
         "averages_counts": averages_counts,
         "averages_clusters": chunked_nanmean(clusters, step),
         "averages_size": chunked_nanmean(sizes, step),
         "averages_brightness": chunked_nanmean(brightness, step),
         "times": times,
+        # (not in the reference) min |metric - flow_threshold| over the frames computed in this run; None when no chunk
+        # went through the fused path (all from checkpoints, or a replaced stage / plotting run)
+        "min_flow_margin": min((m["min_margin"] for m in margins), default=None),
     }
 
 

@@ -79,6 +79,7 @@ PROTOTYPES = {
     "ipx_host_unregister": (_i, [_p]),
     "ipx_upload_frames": (_i, [_ctx, _p, C.c_size_t, _p]),
     "ipx_bgr2gray": (_i, [_ctx, _p, C.c_size_t, _p]),
+    "ipx_unpack_dib": (_i, [_ctx, _p, C.c_size_t, _i, _i, _i, _i, _i, _i, _p]),
     "ipx_flow_metric": (_i, [_ctx, _p, _i, _i, _i, _p, _p, _p]),
     "ipx_flow_status": (_i, [_ctx, C.POINTER(_i), _i]),
     "ipx_debug_fi_spin_limit": (_i, [_ctx, C.c_uint]),
@@ -102,6 +103,8 @@ PROTOTYPES = {
     "ipx_group_set_params": (_i, [_p, C.POINTER(Params)]),
     "ipx_group_info": (_i, [_p, C.POINTER(_i), C.POINTER(_i)]),
     "ipx_group_detect_chunk": (_i, [_p, _p, _i, _i, _i, _p, _i, _p, _p, _p, _p]),
+    "ipx_group_submit": (_i, [_p, _p, _i, _i, _i, _p, _i, _p, _p, _p, _p]),
+    "ipx_group_wait": (_i, [_p]),
     "ipx_pack_mask": (_i, [_ctx, _p, _i, _i, _i, _p]),
     "ipx_unpack_mask": (_i, [_ctx, _p, _i, _i, _i, _p]),
 }

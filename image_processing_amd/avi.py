@@ -172,6 +172,58 @@ class AviReader:
         a = np.frombuffer(self._mm, dtype=np.uint8, count=self._stride * h, offset=off).reshape(h, self._stride)
         np.copyto(out, (a[::-1] if self._bottom_up else a)[:, :w])
 
+    def record_layout(self, start, end):
+        """Frames [start, end) as one region of the file: (file offset of frame ``start``'s pixel data, bytes from one
+        frame's data to the next, bytes of the region) when they are evenly spaced and complete (how every plain
+        uncompressed AVI stores them: '00db' + size + DIB, nothing in between), else None."""
+        if not 0 <= start < end <= len(self._frames):
+            return None
+        need = self._stride * self.height
+        off0, ln0 = self._frames[start]
+        if ln0 < need:
+            return None
+        if end - start == 1:
+            return off0, need, need
+        rec = self._frames[start + 1][0] - off0
+        if rec < need:
+            return None
+        for k in range(start, end):
+            off, ln = self._frames[k]
+            if off != off0 + (k - start) * rec or ln < need:
+                return None
+        return off0, rec, (end - start - 1) * rec + need
+
+    def read_region_into(self, offset, out, threads=4, piece=32 << 20):
+        """``len(out)`` bytes of the file from ``offset`` into ``out`` (a writable, contiguous uint8 buffer, e.g. pinned
+        memory): a few large positional reads from the page cache, in parallel (they release the GIL)."""
+        mv = memoryview(out).cast("B")
+        total = len(mv)
+        fd = self._fh.fileno()
+        spans = [(a, min(total, a + piece)) for a in range(0, total, piece)]
+
+        def one(span):
+            a, b = span
+            while a < b:
+                got = os.preadv(fd, [mv[a:b]], offset + a)
+                if got <= 0:
+                    raise OSError("short read from %s" % self.filename)
+                a += got
+        if threads <= 1 or len(spans) <= 1:
+            for sp in spans:
+                one(sp)
+        else:
+            from concurrent.futures import ThreadPoolExecutor
+            with ThreadPoolExecutor(max_workers=min(threads, len(spans))) as pool:
+                list(pool.map(one, spans))
+
+    @property
+    def stride(self):
+        return self._stride
+
+    @property
+    def bottom_up(self):
+        return self._bottom_up
+
     def close(self):
         if self._mm is not None:
             try:

@@ -1,5 +1,7 @@
 // api.hip -- context, error reporting, parameters, small helper kernels of libipx.so.
 #include "ipx_internal.h"
+#include <dlfcn.h>
+#include <stdlib.h>
 #include <math.h>
 #include <stdarg.h>
 #include <string.h>
@@ -222,6 +224,34 @@ extern "C" int ipx_timer_end(ipx_ctx *ctx, float *elapsed_ms)
     return IPX_OK;
 }
 
+// ---- roctx ranges ---------------------------------------------------------------------------
+namespace {
+struct Roctx {
+    int (*push)(const char *) = nullptr;
+    int (*pop)(void) = nullptr;
+    Roctx()
+    {
+        const char *env = getenv("IPX_ROCTX");
+        if (env && env[0] == '0') return;
+        // (rocprofv3 listens to the rocprofiler-sdk flavour of roctx; the roctracer one is the fallback)
+        static const char *const names[] = {"librocprofiler-sdk-roctx.so.1", "librocprofiler-sdk-roctx.so", "/opt/rocm/lib/librocprofiler-sdk-roctx.so",
+                                            "libroctx64.so.4", "libroctx64.so", "/opt/rocm/lib/libroctx64.so"};
+        for (const char *n : names) {
+            void *h = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+            if (!h) continue;
+            push = (int (*)(const char *))dlsym(h, "roctxRangePushA");
+            pop = (int (*)(void))dlsym(h, "roctxRangePop");
+            if (push && pop) return;
+            push = nullptr; pop = nullptr;
+        }
+    }
+};
+const Roctx &roctx() { static const Roctx r; return r; }     // thread-safe initialisation (C++11)
+}  // namespace
+
+void ipx_range_push(const char *name) { if (roctx().push) (void)roctx().push(name); }
+void ipx_range_pop(void) { if (roctx().pop) (void)roctx().pop(); }
+
 // ---- built-in profiler ----------------------------------------------------------------------
 static const char *const g_kid_names[KID_COUNT] = {
     "pyr_level", "polyexp", "flow_iter",
@@ -346,7 +376,71 @@ __global__ void unpack_kernel(const uint64_t *bits, int rows, int W, int wpr, ui
     mask[i] = (bits[row * wpr + (x >> 6)] >> (x & 63)) & 1;
 }
 
+// Frames as an uncompressed AVI stores them (DIBs: rows of `stride` bytes, padded to 4, usually bottom-up; frame i at
+// raw + i * rec) -> the (n,H,W) top-down uint8 frames cv2.VideoCapture + cvtColor hand to the path (ip.py:62-85).
+// 8-bit streams (grey ramp palette): a copy with the rows turned over.  VEC = 4: four pixels per thread as one dword
+// (W % 4 == 0 and 4-byte aligned records), else byte by byte.
+template <int VEC>
+__global__ void dib8_unpack_kernel(const uint8_t *raw, size_t rec, int n, int H, int W, int stride, int bottom_up, uint8_t *frames)
+{
+    const size_t per_row = (size_t)(W / VEC);
+    const size_t total = (size_t)n * H * per_row;
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t step = (size_t)gridDim.x * blockDim.x;
+    for (; i < total; i += step) {
+        const size_t row = i / per_row;
+        const int x = (int)(i - row * per_row) * VEC;
+        const size_t f = row / H;
+        const int y = (int)(row - f * H);
+        const uint8_t *src = raw + f * rec + (size_t)(bottom_up ? H - 1 - y : y) * stride + x;
+        uint8_t *dst = frames + row * W + x;
+        if (VEC == 4) *reinterpret_cast<uint32_t *>(dst) = *reinterpret_cast<const uint32_t *>(src);
+        else *dst = *src;
+    }
+}
+
+// 24-bit streams: the same walk with OpenCV's fixed-point luma (bgr2gray_kernel) applied on the way.
+__global__ void dib24_gray_kernel(const uint8_t *raw, size_t rec, int n, int H, int W, int stride, int bottom_up, uint8_t *frames)
+{
+    const size_t total = (size_t)n * H * W;
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t step = (size_t)gridDim.x * blockDim.x;
+    for (; i < total; i += step) {
+        const size_t row = i / W;
+        const int x = (int)(i - row * W);
+        const size_t f = row / H;
+        const int y = (int)(row - f * H);
+        const uint8_t *src = raw + f * rec + (size_t)(bottom_up ? H - 1 - y : y) * stride + 3 * (size_t)x;
+        const unsigned b = src[0], g = src[1], r = src[2];
+        frames[i] = (uint8_t)((b * 3735u + g * 19235u + r * 9798u + 16384u) >> 15);
+    }
+}
+
 }  // namespace
+
+extern "C" int ipx_unpack_dib(ipx_ctx *ctx, const uint8_t *raw, size_t rec_bytes, int n, int H, int W, int bits_per_pixel,
+                              int stride, int bottom_up, uint8_t *frames)
+{
+    IPX_REQUIRE(ctx && raw && frames, "null pointer");
+    IPX_REQUIRE(n > 0 && H > 0 && W > 0, "bad sizes");
+    IPX_REQUIRE(bits_per_pixel == 8 || bits_per_pixel == 24, "8-bit (grey ramp) or 24-bit BGR frames");
+    IPX_REQUIRE(stride >= W * (bits_per_pixel / 8) && rec_bytes >= (size_t)stride * H, "rows / records shorter than the image");
+    if (int e = ipx_ctx_enter(ctx)) return e;
+    const size_t P = (size_t)n * H * W;
+    if (bits_per_pixel == 8) {
+        const bool vec = (W & 3) == 0 && (stride & 3) == 0 && (rec_bytes & 3) == 0 && (reinterpret_cast<uintptr_t>(raw) & 3) == 0 &&
+                         (reinterpret_cast<uintptr_t>(frames) & 3) == 0;
+        const size_t items = vec ? P / 4 : P;
+        const unsigned blocks = (unsigned)((items + 255) / 256 < 65536 ? (items + 255) / 256 : 65536);
+        if (vec) IPX_LAUNCH(ctx, KID_MISC, 2.0 * P, dib8_unpack_kernel<4>, dim3(blocks), dim3(256), raw, rec_bytes, n, H, W, stride, bottom_up, frames);
+        else IPX_LAUNCH(ctx, KID_MISC, 2.0 * P, dib8_unpack_kernel<1>, dim3(blocks), dim3(256), raw, rec_bytes, n, H, W, stride, bottom_up, frames);
+    } else {
+        const unsigned blocks = (unsigned)((P + 255) / 256 < 65536 ? (P + 255) / 256 : 65536);
+        IPX_LAUNCH(ctx, KID_MISC, 4.0 * P, dib24_gray_kernel, dim3(blocks), dim3(256), raw, rec_bytes, n, H, W, stride, bottom_up, frames);
+    }
+    IPX_LAUNCH_CHECK();
+    return IPX_OK;
+}
 
 extern "C" int ipx_bgr2gray(ipx_ctx *ctx, const uint8_t *bgr, size_t npix, uint8_t *gray)
 {

@@ -563,7 +563,8 @@ extern "C" int ipx_cluster_stats(ipx_ctx *ctx, const uint8_t *frames, const uint
     const Plane pl = make_plane(H, W);
     // per plane: parent + aux0 + aux1 (4 bytes per id each) + the closed plane
     const size_t per_plane = pl.ids * 12 + pl.words * 8;
-    const int B = ccl_batch(pl, n, per_plane, CCL_BUDGET);
+    int B = ccl_batch(pl, n, per_plane, CCL_BUDGET);
+    if (B > 65535) B = 65535;                            // close_cross3_kernel takes the batch's planes in grid.z
     void *scr;
     if (int e = ipx_scratch(ctx, SLOT_CCL, per_plane * B, &scr)) return e;
     int *par = (int *)scr;

@@ -49,15 +49,38 @@ extern "C" int ipx_detect_chunk(ipx_ctx *ctx, const uint8_t *frames, int n, int 
     int64_t *dense2 = (int64_t *)cnt, *fin3 = dense2 + 2 * (size_t)n;
     int32_t *heat = (int32_t *)maps, *valid = heat + P;
 
-    IPX_TRY(ipx_flow_metric(ctx, frames, n, H, W, nullptr, flows, keep));                         // ip.py:554, :559
-    IPX_TRY(ipx_detect_raw(ctx, frames, n, H, W, 0, n, keep, (uint64_t *)raw, (uint64_t *)bright, dense2));   // :560-565
-    IPX_TRY(ipx_remove_bright_regions(ctx, (const uint64_t *)bright, (const uint64_t *)raw, n, H, W, (uint64_t *)raw));   // :566
-    // (no keep list: the raw planes of discarded frames are all zero here, which resets the runs just the same)
-    IPX_TRY(ipx_persistent_mask(ctx, (const uint64_t *)raw, nullptr, n, H, W, (uint64_t *)pers));    // :575
-    IPX_TRY(ipx_static_maps(ctx, frames, (const uint64_t *)raw, (const uint64_t *)pers, nullptr, n, H, W, heat, valid));   // :580-590
-    IPX_TRY(ipx_static_from_maps(ctx, heat, valid, H, W, (uint64_t *)stat));
-    IPX_TRY(ipx_finalize(ctx, frames, (const uint64_t *)raw, (const uint64_t *)pers, (const uint64_t *)stat, keep, n, H, W,
-                         (uint64_t *)fin, fin3));                                                 // :592-605
-    IPX_TRY(ipx_cluster_stats(ctx, frames, (const uint64_t *)fin, keep, n, H, W, pow2_table, tdim, cluster, nullptr));   // :608
+    // (each stage's enqueue sits in a roctx range named after the reference function it replaces)
+    ipx_range whole("ipx_detect_chunk");
+    {
+        ipx_range r("compute_optical_flow_metric");
+        IPX_TRY(ipx_flow_metric(ctx, frames, n, H, W, nullptr, flows, keep));                     // ip.py:554, :559
+    }
+    {
+        ipx_range r("compute_background+_raw_damaged_mask");
+        IPX_TRY(ipx_detect_raw(ctx, frames, n, H, W, 0, n, keep, (uint64_t *)raw, (uint64_t *)bright, dense2));   // :560-565
+    }
+    {
+        ipx_range r("remove_bright_regions");
+        IPX_TRY(ipx_remove_bright_regions(ctx, (const uint64_t *)bright, (const uint64_t *)raw, n, H, W, (uint64_t *)raw));   // :566
+    }
+    {
+        ipx_range r("compute_persistent_mask");
+        // (no keep list: the raw planes of discarded frames are all zero here, which resets the runs just the same)
+        IPX_TRY(ipx_persistent_mask(ctx, (const uint64_t *)raw, nullptr, n, H, W, (uint64_t *)pers));    // :575
+    }
+    {
+        ipx_range r("filter_consecutive_pixels+compute_static_mask");
+        IPX_TRY(ipx_static_maps(ctx, frames, (const uint64_t *)raw, (const uint64_t *)pers, nullptr, n, H, W, heat, valid));   // :580-590
+        IPX_TRY(ipx_static_from_maps(ctx, heat, valid, H, W, (uint64_t *)stat));
+    }
+    {
+        ipx_range r("apply_static_suppression+bright_area_counters");
+        IPX_TRY(ipx_finalize(ctx, frames, (const uint64_t *)raw, (const uint64_t *)pers, (const uint64_t *)stat, keep, n, H, W,
+                             (uint64_t *)fin, fin3));                                             // :592-605
+    }
+    {
+        ipx_range r("compute_cluster_stats");
+        IPX_TRY(ipx_cluster_stats(ctx, frames, (const uint64_t *)fin, keep, n, H, W, pow2_table, tdim, cluster, nullptr));   // :608
+    }
     return ipx_merge_counts(ctx, fin3, dense2, n, counts);
 }

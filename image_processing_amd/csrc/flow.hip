@@ -1184,14 +1184,23 @@ int pair_batch(int H, int W, int want)
     return (int)b;
 }
 
-// SLOT_FLOW_RED = [error word (256 bytes) | partial sums].  The word is cleared when the slot is (re)made and
-// stays raised once a kernel has raised it (sticky until ipx_flow_status(..., clear) or a new arena).
+// SLOT_FLOW_RED = [error word (256 bytes) | partial sums].  The word starts at zero and stays raised once a kernel
+// has raised it: sticky until ipx_flow_status(..., clear), also when the slot has to grow (the word of the old arena
+// is read before that arena is freed and carried over into the new one).
 int flow_red(ipx_ctx *ctx, size_t partial_bytes, void **partial, unsigned **err)
 {
     const bool fresh = ctx->slot_bytes[SLOT_FLOW_RED] < partial_bytes + 256;
+    unsigned carried = 0;
+    if (fresh && ctx->flow_ran && ctx->slot[SLOT_FLOW_RED]) {
+        IPX_CHECK_HIP(hipMemcpyAsync(&carried, ctx->slot[SLOT_FLOW_RED], sizeof(carried), hipMemcpyDeviceToHost, ctx->stream));
+        IPX_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+    }
     void *base;
     IPX_TRY(ipx_scratch(ctx, SLOT_FLOW_RED, partial_bytes + 256, &base));
-    if (fresh) IPX_CHECK_HIP(hipMemsetAsync(base, 0, 256, ctx->stream));
+    if (fresh) {
+        IPX_CHECK_HIP(hipMemsetAsync(base, 0, 256, ctx->stream));
+        if (carried) IPX_CHECK_HIP(hipMemsetD32Async((hipDeviceptr_t)base, (int)carried, 1, ctx->stream));
+    }
     *err = (unsigned *)base;
     *partial = (char *)base + 256;
     ctx->flow_ran = 1;

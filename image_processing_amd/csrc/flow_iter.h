@@ -6,9 +6,6 @@
 #ifndef IPX_FI_C_BPERMUTE
 #define IPX_FI_C_BPERMUTE 0      // 1: phase C exchanges its pair and quad sums with ds_bpermute (the round-2 form)
 #endif
-#ifndef IPX_FI_PK
-#define IPX_FI_PK 1              // 1: the producers' matrix arithmetic on channel pairs (v_pk_mul_f32 / v_pk_add_f32), same bits
-#endif
 // Ablation builds (tools/fi_ablate.py, timing only, results are garbage): bit 0 = the consumer waves do no work,
 // bit 1 = the second expansion is sampled from the pair's first frame (its lines are L1 hits), bit 2 = the
 // producers replace the matrix arithmetic by plain sums of what they loaded, bit 3 = one of the four bilinear taps

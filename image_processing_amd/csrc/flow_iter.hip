@@ -12,24 +12,12 @@ namespace {
 // FarnebackUpdateMatrices at one pixel: the five entries (G11, G12, G22, h1, h2) from the
 // expansions R0 (at the pixel) and R1 (bilinear sample at pixel + flow), with border damping.
 // Split into the loads and the arithmetic so that a caller can keep the loads in flight.
-#if IPX_FI_PK
-typedef float fi_v2 __attribute__((ext_vector_type(2)));
-struct UmIn {           // the loaded vectors as they arrive: adjacent registers hold the channel pairs the arithmetic works on
-    fi_v2 r01, r23;     // R0 at the pixel, coefficients (0,1) and (2,3)
-    float r4;           //                  coefficient 4
-    fi_v2 q01[4], q23[4];   // R1 at (x1,y1), (x1+1,y1), (x1,y1+1), (x1+1,y1+1); unset when the sample is out of bounds
-    float q4[4];
-    float fx, fy;       // fractions of the sample position (um_position), kept from the loads to the arithmetic
-    bool inb;           // the sample is inside the second image
-};
-#else
 struct UmIn {
     float r0[5];        // R0 at the pixel
     float q[5][4];      // R1 at (x1,y1), (x1+1,y1), (x1,y1+1), (x1+1,y1+1); unset when the sample is out of bounds
     float fx, fy;       // fractions of the sample position (um_position), kept from the loads to the arithmetic
     bool inb;           // the sample is inside the second image
 };
-#endif
 
 // bilinear sample position of pixel (x,y) displaced by d: integer corner, fractions, in-bounds test
 __device__ __forceinline__ bool um_position(float2 d, int x, int y, int h, int w, int &x1, int &y1, float &fx, float &fy)
@@ -47,18 +35,17 @@ __device__ __forceinline__ bool um_position(float2 d, int x, int y, int h, int w
 // offset of the fifth coefficient's plane.  16-byte loads fetch coefficients 0-3 of one pixel; the loads are
 // unconditional (no divergent control flow between issue and use).  A position that must not be read (a matrix
 // column or row that feeds nothing, a sample outside the image) is replaced by pixel index UM_DEAD ONCE, before
-// the offsets are derived from it: 16 * UM_DEAD lies beyond any resource (frames have at most 2^26 pixels, a
-// resource at most 40 * 2^26 bytes), so the 16-byte loads fetch nothing and return 0; the 4-byte plane's offset
-// 4 * UM_DEAD is beyond the resource for frames of up to 2^23 pixels and a harmless read inside it for larger
-// ones -- what such a load returns is never used.  The +16 / +1 row steps come after the select, so they fold
-// into the instructions' immediate offsets or cost one addition for both planes.
-// (Measured A/B, round 2: with the row's share of every offset moved into the loads' scalar offsets -- 16 of the producers'
-// 210 vector instructions per step fewer -- and the field loaded and stored through buffers the same way, the kernel took the
-// same time to within 0.3 %: the producers have slack, the consumer waves set the pace.)
-// The expansions are loaded with the default cache policy: marked non-temporal, the loads of the pair's first frame
-// cost the kernel 6 % and the bilinear taps 48 % (measured A/B) -- every line is wanted again, by the neighbouring
-// taps and by the pair that follows.
-constexpr unsigned UM_DEAD = 0x0f000000u;
+// the offsets are derived from it.  UM_DEAD = 0x3ffffff0 puts BOTH derived offsets beyond any resource this kernel
+// is given (frames have at most 2^26 pixels, a resource at most 40 * 2^26 = 0xa0000000 bytes): the 4-byte plane's
+// offset is 4 * UM_DEAD = 0xffffffc0 and the 16-byte planes' is 16 * UM_DEAD mod 2^32 = 0xffffff00, so the range check
+// (which sees the vector offset alone, not the scalar one) fails for the loads at the position itself and they fetch
+// nothing.  The loads one ROW further down add w * 16 resp. w * 4 in 32-bit arithmetic and wrap to a small offset:
+// they read a few bytes near the start of the second frame's planes (inside the resource and the allocation:
+// harmless) and what they return is never used.  The +16 / +1 row steps come after the select, so they fold into the
+// instructions' immediate offsets or cost one addition for both planes.
+// (Round 2 used 0x0f000000, whose 4-byte offset 0x3c000000 is INSIDE the resource of frames above 25.2 M pixels and
+// was then displaced by the scalar offset to beyond the allocation: ADVICE r2, tests/test_gpu_chunk.py::test_flow_above_25_megapixels.)
+constexpr unsigned UM_DEAD = 0x3ffffff0u;
 __device__ __forceinline__ void um_load(__amdgpu_buffer_rsrc_t rR, unsigned FS, unsigned P16, float2 d, int x, int y, int h, int w,
                                         UmIn &in, bool live = true)
 {
@@ -69,16 +56,9 @@ __device__ __forceinline__ void um_load(__amdgpu_buffer_rsrc_t rR, unsigned FS, 
 #endif
     in.inb = um_position(d, x, y, h, w, x1, y1, in.fx, in.fy);
     const ipx_u32x4 c03 = __builtin_amdgcn_raw_buffer_load_b128(rR, o1 * 16u, 0, 0);
-    const float c4 = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rR, o1 * 4u, P16, 0));
-#if IPX_FI_PK
-    in.r4 = c4;
-    in.r01 = fi_v2{__uint_as_float(c03.x), __uint_as_float(c03.y)};
-    in.r23 = fi_v2{__uint_as_float(c03.z), __uint_as_float(c03.w)};
-#else
-    in.r0[4] = c4;
+    in.r0[4] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rR, o1 * 4u, P16, 0));
     in.r0[0] = __uint_as_float(c03.x); in.r0[1] = __uint_as_float(c03.y);
     in.r0[2] = __uint_as_float(c03.z); in.r0[3] = __uint_as_float(c03.w);
-#endif
     const unsigned q1 = in.inb && live ? (unsigned)(y1 * w + x1) : UM_DEAD;
     const unsigned qa = q1 * 16u, qb = qa + 16u * (unsigned)w, qe = q1 * 4u;
     const ipx_u32x4 s00 = __builtin_amdgcn_raw_buffer_load_b128(rR, qa, FS, 0);
@@ -94,68 +74,13 @@ __device__ __forceinline__ void um_load(__amdgpu_buffer_rsrc_t rR, unsigned FS, 
     const ipx_u32x2 e0 = __builtin_amdgcn_raw_buffer_load_b64(rR, qe, FS + P16, 0);
     const ipx_u32x2 e1 = __builtin_amdgcn_raw_buffer_load_b64(rR, qe + 4u * (unsigned)w, FS + P16, 0);
 #endif
-#if IPX_FI_PK
-    auto lo = [](ipx_u32x4 v) { return fi_v2{__uint_as_float(v.x), __uint_as_float(v.y)}; };
-    auto hi = [](ipx_u32x4 v) { return fi_v2{__uint_as_float(v.z), __uint_as_float(v.w)}; };
-    in.q01[0] = lo(s00); in.q01[1] = lo(s01); in.q01[2] = lo(s10); in.q01[3] = lo(s11);
-    in.q23[0] = hi(s00); in.q23[1] = hi(s01); in.q23[2] = hi(s10); in.q23[3] = hi(s11);
-    in.q4[0] = __uint_as_float(e0.x); in.q4[1] = __uint_as_float(e0.y); in.q4[2] = __uint_as_float(e1.x); in.q4[3] = __uint_as_float(e1.y);
-#else
     in.q[0][0] = __uint_as_float(s00.x); in.q[0][1] = __uint_as_float(s01.x); in.q[0][2] = __uint_as_float(s10.x); in.q[0][3] = __uint_as_float(s11.x);
     in.q[1][0] = __uint_as_float(s00.y); in.q[1][1] = __uint_as_float(s01.y); in.q[1][2] = __uint_as_float(s10.y); in.q[1][3] = __uint_as_float(s11.y);
     in.q[2][0] = __uint_as_float(s00.z); in.q[2][1] = __uint_as_float(s01.z); in.q[2][2] = __uint_as_float(s10.z); in.q[2][3] = __uint_as_float(s11.z);
     in.q[3][0] = __uint_as_float(s00.w); in.q[3][1] = __uint_as_float(s01.w); in.q[3][2] = __uint_as_float(s10.w); in.q[3][3] = __uint_as_float(s11.w);
     in.q[4][0] = __uint_as_float(e0.x); in.q[4][1] = __uint_as_float(e0.y); in.q[4][2] = __uint_as_float(e1.x); in.q[4][3] = __uint_as_float(e1.y);
-#endif
 }
 
-#if IPX_FI_PK
-// The matrix arithmetic on PAIRS of channels (v_pk_mul_f32 / v_pk_add_f32: two IEEE f32 operations per lane and instruction,
-// each rounded as the single instruction rounds it, so the results are the scalar form's bit for bit).  The pairs are the ones
-// the 16-byte loads deliver in adjacent registers: coefficients (0,1) feed (r2,r3), coefficients (2,3) feed (r4,r5); every
-// expression of FarnebackUpdateMatrices is then one packed operation for two values, with the operand order of the scalar
-// form kept wherever an addition is not commutative in its rounding (it always is: a + b == b + a; only the association counts).
-__device__ __forceinline__ fi_v2 fi_splat(float v) { return fi_v2{v, v}; }
-__device__ __forceinline__ void um_finish(const UmIn &in, float2 d, int x, int y, int h, int w, float (&m)[5])
-{
-    const float dx = d.x, dy = d.y;
-    const float fx = in.fx, fy = in.fy;
-    const bool inb = in.inb;
-    const fi_v2 r0a = in.r01, r0b = in.r23;
-    fi_v2 r23, r45;
-    float r6;
-    if (inb) {
-        const float a00 = (1.f - fx) * (1.f - fy), a01 = fx * (1.f - fy), a10 = (1.f - fx) * fy, a11 = fx * fy;
-        const fi_v2 A00 = fi_splat(a00), A01 = fi_splat(a01), A10 = fi_splat(a10), A11 = fi_splat(a11);
-        r23 = A00 * in.q01[0] + A01 * in.q01[1] + A10 * in.q01[2] + A11 * in.q01[3];
-        r45 = A00 * in.q23[0] + A01 * in.q23[1] + A10 * in.q23[2] + A11 * in.q23[3];
-        r6 = a00 * in.q4[0] + a01 * in.q4[1] + a10 * in.q4[2] + a11 * in.q4[3];
-        r45 = (r0b + r45) * fi_splat(0.5f);
-        r6 = (in.r4 + r6) * 0.25f;
-    } else {
-        r23 = fi_splat(0.f);
-        r45 = r0b;
-        r6 = in.r4 * 0.5f;
-    }
-    r23 = (r0a - r23) * fi_splat(0.5f);
-    // r2 += r4 * dy + r6 * dx;  r3 += r6 * dy + r5 * dx
-    r23 += r45 * fi_v2{dy, dx} + fi_splat(r6) * fi_v2{dx, dy};
-    constexpr int BORDER = 5;
-    if ((unsigned)(x - BORDER) >= (unsigned)(w - BORDER * 2) || (unsigned)(y - BORDER) >= (unsigned)(h - BORDER * 2)) {
-        auto bw = [](int i) -> float { return i < 2 ? 0.14f : 0.4472f; };   // {0.14, 0.14, 0.4472, 0.4472, 0.4472}
-        const float scale = (x < BORDER ? bw(x) : 1.f) * (x >= w - BORDER ? bw(w - x - 1) : 1.f) *
-                            (y < BORDER ? bw(y) : 1.f) * (y >= h - BORDER ? bw(h - y - 1) : 1.f);
-        r23 *= fi_splat(scale); r45 *= fi_splat(scale); r6 *= scale;
-    }
-    const fi_v2 m02 = r45 * r45 + fi_splat(r6 * r6);                    // r4*r4 + r6*r6, r5*r5 + r6*r6
-    const fi_v2 m34 = r45 * r23 + fi_splat(r6) * fi_v2{r23.y, r23.x};   // r4*r2 + r6*r3, r5*r3 + r6*r2 (= r6*r2 + r5*r3)
-    m[0] = m02.x;
-    m[1] = (r45.x + r45.y) * r6;
-    m[2] = m02.y;
-    m[3] = m34.x;
-    m[4] = m34.y;
-}
-#else
 __device__ __forceinline__ void um_finish(const UmIn &in, float2 d, int x, int y, int h, int w, float (&m)[5])
 {
 #if IPX_FI_ABLATE & 4
@@ -199,7 +124,6 @@ __device__ __forceinline__ void um_finish(const UmIn &in, float2 d, int x, int y
     m[3] = r4 * r2 + r6 * r3;
     m[4] = r6 * r2 + r5 * r3;
 }
-#endif
 
 // One Farneback iteration, fused: FarnebackUpdateMatrices -> 15x15 box window (replicate borders,
 // f64) -> regularised 2x2 solve.  The matrices never touch HBM.  A 512-thread workgroup owns a strip of

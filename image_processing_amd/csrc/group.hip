@@ -16,12 +16,20 @@
 //   IPX_GROUP_PEER  hipMemcpyPeerAsync from the neighbours' buffers, ordered by events and host barriers; also
 //                   works when a device is listed more than once (how the sharding logic is tested on one GPU).
 // Per-frame results go straight from every rank into the caller's HOST arrays (no collective).
+//
+// Two chunks may be in flight (ipx_group_submit / ipx_group_wait): every rank has two frame buffers and a side
+// stream, and a chunk's frames are uploaded AT SUBMIT TIME, by the submitting thread, into the buffer the chunk
+// before it does not use -- so the upload of chunk k+1 runs under the compute of chunk k (at 8 ranks x 125 frames of
+// 1080p a rank uploads 0.27 GB for ~15 ms of compute: without the overlap the path is PCIe-bound by construction).
+// The ranks' host threads take the chunks strictly in order; ipx_group_detect_chunk = submit + wait.
 #include "ipx_internal.h"
 #include <dlfcn.h>
 #include <string.h>
 #include <atomic>
 #include <condition_variable>
+#include <deque>
 #include <mutex>
+#include <string>
 #include <thread>
 #include <vector>
 
@@ -38,6 +46,7 @@ struct Rccl {
     void *handle = nullptr;
     int (*CommInitAll)(ncclComm_t *, int, const int *) = nullptr;
     int (*CommDestroy)(ncclComm_t) = nullptr;
+    int (*CommAbort)(ncclComm_t) = nullptr;
     int (*AllGather)(const void *, void *, size_t, int, ncclComm_t, hipStream_t) = nullptr;
     int (*AllReduce)(const void *, void *, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
     const char *(*GetErrorString)(int) = nullptr;
@@ -53,6 +62,7 @@ bool rccl_load(Rccl &r)
     if (!r.handle) return false;
     r.CommInitAll = (decltype(r.CommInitAll))dlsym(r.handle, "ncclCommInitAll");
     r.CommDestroy = (decltype(r.CommDestroy))dlsym(r.handle, "ncclCommDestroy");
+    r.CommAbort = (decltype(r.CommAbort))dlsym(r.handle, "ncclCommAbort");      // optional: only used after a failure
     r.AllGather = (decltype(r.AllGather))dlsym(r.handle, "ncclAllGather");
     r.AllReduce = (decltype(r.AllReduce))dlsym(r.handle, "ncclAllReduce");
     r.GetErrorString = (decltype(r.GetErrorString))dlsym(r.handle, "ncclGetErrorString");
@@ -88,8 +98,10 @@ __global__ void sum_i32_kernel(const int32_t *stack, int count, size_t n, int32_
 struct Rank {
     int device = 0;
     ipx_ctx *ctx = nullptr;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr, up_stream = nullptr;
     hipEvent_t ev_raw = nullptr, ev_pers = nullptr, ev_maps = nullptr;
+    hipEvent_t ev_up[2] = {nullptr, nullptr};   // frames of the chunk in frame buffer 0 / 1 have arrived
+    uint8_t *ext[2] = {nullptr, nullptr};       // this rank's frames (+ halo) of the chunk in that buffer
     ncclComm_t comm = nullptr;
     // what the neighbours read (published before the barrier that precedes the read)
     uint64_t *raw = nullptr;       // own raw planes [nown]
@@ -102,13 +114,20 @@ struct Rank {
 
 }  // namespace
 
+struct GroupCall;
+
 struct ipx_group {
     int nd = 0, transport = IPX_GROUP_PEER;
     std::vector<Rank> ranks;
     Rccl rccl;
     HostBarrier barrier;
     ipx_params p;
-    std::atomic<bool> failed{false};
+    // chunks in flight, oldest first (at most two); the ranks' threads take them strictly in order
+    std::mutex m;
+    std::condition_variable cv;
+    std::deque<GroupCall *> inflight;
+    unsigned long submitted = 0, completed = 0;
+    bool broken = false;                       // an RCCL collective was abandoned: the communicator is gone
 };
 
 namespace {
@@ -119,42 +138,56 @@ inline void shard_range(int n, int r, int nd, int &a, int &b)
     b = (int)(((long long)(r + 1) * n) / nd);
 }
 
-struct Call {
+}  // namespace
+
+// One submitted chunk.
+struct GroupCall {
     ipx_group *g;
     const uint8_t *frames; int n, H, W;
-    const double *pow2; int tdim;
+    std::vector<double> tab; int tdim;         // the caller's pow2 table, copied at submit
     float *flows; uint8_t *keep; int64_t *counts; int64_t *cluster;
+    ipx_params p;
+    int buf;                                   // frame buffer / upload event of this chunk (0 / 1)
+    unsigned long seq;
+    std::atomic<bool> failed{false};
+    std::atomic<int> ranks_left{0};
+    std::vector<std::thread> th;
+    std::vector<int> status;                   // per rank, final (the ranks' own fields are reused by the next chunk)
+    std::vector<std::string> error;
 };
+typedef GroupCall Call;
 
-void rank_fail(ipx_group *g, Rank &rk, int status)
+namespace {
+
+void rank_fail(Call &c, Rank &rk, int status)
 {
     rk.status = status;
     snprintf(rk.error, sizeof(rk.error), "%s", ipx_last_error());
-    g->failed.store(true);  // only ever set during a call; the ranks read it through the next barrier
+    c.failed.store(true);   // only ever set during the call; the ranks read it through the next barrier
 }
 
 #define RK_TRY(expr)                                                                     \
     do {                                                                                 \
-        if (rk.status == IPX_OK) { const int s_ = (expr); if (s_ != IPX_OK) rank_fail(g, rk, s_); } \
+        if (rk.status == IPX_OK) { const int s_ = (expr); if (s_ != IPX_OK) rank_fail(c, rk, s_); } \
     } while (0)
 #define RK_HIP(expr)                                                                     \
     do {                                                                                 \
         if (rk.status == IPX_OK) {                                                       \
             const hipError_t e_ = (expr);                                                \
-            if (e_ != hipSuccess) { ipx_set_error("%s failed: %s (group rank %d)", #expr, hipGetErrorString(e_), r); rank_fail(g, rk, IPX_ERR_HIP); } \
+            if (e_ != hipSuccess) { ipx_set_error("%s failed: %s (group rank %d)", #expr, hipGetErrorString(e_), r); rank_fail(c, rk, IPX_ERR_HIP); } \
         }                                                                                \
     } while (0)
 #define RK_NCCL(expr)                                                                    \
     do {                                                                                 \
         if (rk.status == IPX_OK) {                                                       \
             const int e_ = (expr);                                                       \
-            if (e_ != 0) { ipx_set_error("%s failed: %s (group rank %d)", #expr, g->rccl.GetErrorString(e_), r); rank_fail(g, rk, IPX_ERR_HIP); } \
+            if (e_ != 0) { ipx_set_error("%s failed: %s (group rank %d)", #expr, g->rccl.GetErrorString(e_), r); rank_fail(c, rk, IPX_ERR_HIP); } \
         }                                                                                \
     } while (0)
 // every rank passes the same barriers; after one, all ranks see the same `failed` and leave together
-#define RK_SYNC() do { if (g->barrier.wait(g->failed)) return; } while (0)
+#define RK_SYNC() do { if (g->barrier.wait(c.failed)) return; } while (0)
 
-void rank_body(const Call &c, int r)
+void rank_body(Call &c, int r)
 {
     ipx_group *g = c.g;
     Rank &rk = g->ranks[r];
@@ -163,8 +196,8 @@ void rank_body(const Call &c, int r)
     const bool rccl = g->transport == IPX_GROUP_RCCL;
     const bool exchange = nd > 1 || rccl;                  // a world of one still runs its collectives over RCCL
     const size_t P = (size_t)H * W, words = (size_t)H * ipx_wpr(W), plane = words * 8;
-    const int radius = g->p.sliding_window_radius > 1 ? g->p.sliding_window_radius : 1;
-    const int T = g->p.consecutive_threshold, edge = T - 1 > 0 ? T - 1 : 0;
+    const int radius = c.p.sliding_window_radius > 1 ? c.p.sliding_window_radius : 1;
+    const int T = c.p.consecutive_threshold, edge = T - 1 > 0 ? T - 1 : 0;
     int a, b;
     shard_range(n, r, nd, a, b);
     const int lo = a - radius > 0 ? a - radius : 0, hi = b + radius < n ? b + radius : n;
@@ -174,10 +207,10 @@ void rank_body(const Call &c, int r)
     rk.error[0] = 0;
 
     // ---- buffers (context slots: they only grow) and the upload of this rank's frames -----------------------
-    void *ext = nullptr, *misc = nullptr, *stack = nullptr, *bright = nullptr, *pers = nullptr, *stat = nullptr, *fin = nullptr,
+    void *misc = nullptr, *stack = nullptr, *bright = nullptr, *pers = nullptr, *stat = nullptr, *fin = nullptr,
          *maps = nullptr, *cnt = nullptr, *edges = nullptr, *pers_all = nullptr, *maps_all = nullptr;
     RK_HIP(hipSetDevice(rk.device));
-    RK_TRY(ipx_scratch(ctx, GS_FRAMES, (size_t)next * P, &ext));
+    RK_TRY(ipx_set_params(ctx, &c.p));
     const size_t tab_bytes = sizeof(double) * (size_t)c.tdim * c.tdim;
     const size_t misc_bytes = ipx_align_up(tab_bytes, 256) + ipx_align_up((size_t)next, 256) + ipx_align_up((size_t)nown, 256) +
                               ipx_align_up(sizeof(float) * (size_t)nown, 256) + sizeof(int64_t) * 8 * (size_t)nown;
@@ -201,15 +234,16 @@ void rank_body(const Call &c, int r)
     float *d_flows = (float *)mp;                    mp += ipx_align_up(sizeof(float) * (size_t)nown, 256);
     int64_t *d_counts5 = (int64_t *)mp, *d_cluster = d_counts5 + 5 * (size_t)nown;
     int64_t *dense2 = (int64_t *)cnt, *fin3 = dense2 + 2 * (size_t)nown;
-    uint8_t *ext_frames = (uint8_t *)ext;
+    uint8_t *ext_frames = rk.ext[c.buf];                  // uploaded by ipx_group_submit on the side stream
     const uint8_t *own = ext_frames + (size_t)hl * P;
     uint64_t *raw = (uint64_t *)stack + (size_t)edge * words;
     uint64_t *pers_own = (uint64_t *)pers, *pers_merged = pers_own + words;
     int32_t *maps_own = (int32_t *)maps, *maps_sum = maps_own + 2 * P;
     rk.raw = raw; rk.pers = pers_own; rk.maps = maps_own;
     hipStream_t st = rk.stream;
-    RK_HIP(hipMemcpyAsync(ext_frames, c.frames + (size_t)lo * P, (size_t)next * P, hipMemcpyHostToDevice, st));
-    RK_HIP(hipMemcpyAsync(d_tab, c.pow2, tab_bytes, hipMemcpyHostToDevice, st));
+    if (rk.status == IPX_OK && !ext_frames) { ipx_set_error("group rank %d: no frame buffer", r); rank_fail(c, rk, IPX_ERR_HIP); }
+    RK_HIP(hipStreamWaitEvent(st, rk.ev_up[c.buf], 0));
+    RK_HIP(hipMemcpyAsync(d_tab, c.tab.data(), tab_bytes, hipMemcpyHostToDevice, st));
     RK_SYNC();
 
     // ---- motion test, raw planes, bright-region rejection of the owned frames ---------------------------------
@@ -228,6 +262,7 @@ void rank_body(const Call &c, int r)
             uint64_t *mine = (uint64_t *)edges, *all = mine + 2 * (size_t)edge * words;
             RK_HIP(hipMemcpyAsync(mine, raw, plane * edge, hipMemcpyDeviceToDevice, st));
             RK_HIP(hipMemcpyAsync(mine + (size_t)edge * words, raw + (size_t)(nown - edge) * words, plane * edge, hipMemcpyDeviceToDevice, st));
+            RK_SYNC();                                     // nothing fallible between this agreement and the collective
             RK_NCCL(g->rccl.AllGather(mine, all, 2 * (size_t)edge * words, NCCL_UINT64, rk.comm, st));
             if (r > 0) RK_HIP(hipMemcpyAsync(left, all + ((size_t)(r - 1) * 2 + 1) * edge * words, plane * edge, hipMemcpyDeviceToDevice, st));
             else RK_HIP(hipMemsetAsync(left, 0, plane * edge, st));
@@ -299,16 +334,35 @@ void rank_body(const Call &c, int r)
     RK_HIP(hipMemcpyAsync(c.counts + 5 * (size_t)a, d_counts5, sizeof(int64_t) * 5 * (size_t)nown, hipMemcpyDeviceToHost, st));
     RK_HIP(hipMemcpyAsync(c.cluster + 3 * (size_t)a, d_cluster, sizeof(int64_t) * 3 * (size_t)nown, hipMemcpyDeviceToHost, st));
     RK_TRY(ipx_synchronize(ctx));                          // also reports a failure inside the flow stage's kernels
-    (void)g->barrier.wait(g->failed);                      // nobody reuses a buffer a neighbour may still be reading
+    (void)g->barrier.wait(c.failed);                       // nobody reuses a buffer a neighbour may still be reading
 }
 
-void rank_thread(const Call *c, int r)
+void rank_thread(Call *c, int r)
 {
+    ipx_group *g = c->g;
+    {   // chunks are taken strictly in order: wait until every rank is through with the chunk before
+        std::unique_lock<std::mutex> lk(g->m);
+        g->cv.wait(lk, [&] { return g->completed == c->seq; });
+    }
     rank_body(*c, r);
-    // a rank that left early (failure seen after a barrier) still drains its stream before the call returns
-    Rank &rk = c->g->ranks[r];
+    Rank &rk = g->ranks[r];
     (void)hipSetDevice(rk.device);
+    if (c->failed.load() && g->transport == IPX_GROUP_RCCL) {
+        // A rank that failed may have left a collective the others had already enqueued: draining the stream would wait
+        // for it for ever.  Abandon the communicator instead; the group refuses further chunks.
+        if (g->rccl.CommAbort && rk.comm) { (void)g->rccl.CommAbort(rk.comm); rk.comm = nullptr; }
+        std::lock_guard<std::mutex> lk(g->m);
+        g->broken = true;
+    }
+    // a rank that left early (failure seen after a barrier) still drains its stream before the chunk counts as done
     (void)hipStreamSynchronize(rk.stream);
+    c->status[r] = rk.status;
+    c->error[r] = rk.error;
+    if (--c->ranks_left == 0) {
+        std::lock_guard<std::mutex> lk(g->m);
+        ++g->completed;
+        g->cv.notify_all();
+    }
 }
 
 }  // namespace
@@ -354,6 +408,9 @@ extern "C" int ipx_group_create(const int *devices, int ndev, int transport, ipx
         if (e == hipSuccess) e = hipEventCreateWithFlags(&rk.ev_raw, hipEventDisableTiming);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&rk.ev_pers, hipEventDisableTiming);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&rk.ev_maps, hipEventDisableTiming);
+        if (e == hipSuccess) e = hipStreamCreateWithFlags(&rk.up_stream, hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&rk.ev_up[0], hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&rk.ev_up[1], hipEventDisableTiming);
         if (e != hipSuccess) { ipx_set_error("ipx_group_create: %s", hipGetErrorString(e)); status = IPX_ERR_HIP; break; }
         (void)ipx_set_stream(rk.ctx, rk.stream);
         if (transport == IPX_GROUP_PEER)
@@ -377,9 +434,11 @@ extern "C" int ipx_group_create(const int *devices, int ndev, int transport, ipx
 extern "C" int ipx_group_destroy(ipx_group *g)
 {
     if (!g) return IPX_OK;
+    while (!g->inflight.empty()) (void)ipx_group_wait(g);  // chunks the caller never waited for
     for (Rank &rk : g->ranks) {
         (void)hipSetDevice(rk.device);
         if (rk.stream) (void)hipStreamSynchronize(rk.stream);
+        if (rk.up_stream) (void)hipStreamSynchronize(rk.up_stream);
         if (rk.comm) (void)g->rccl.CommDestroy(rk.comm);
     }
     for (Rank &rk : g->ranks) {
@@ -388,6 +447,9 @@ extern "C" int ipx_group_destroy(ipx_group *g)
         if (rk.ev_raw) (void)hipEventDestroy(rk.ev_raw);
         if (rk.ev_pers) (void)hipEventDestroy(rk.ev_pers);
         if (rk.ev_maps) (void)hipEventDestroy(rk.ev_maps);
+        if (rk.ev_up[0]) (void)hipEventDestroy(rk.ev_up[0]);
+        if (rk.ev_up[1]) (void)hipEventDestroy(rk.ev_up[1]);
+        if (rk.up_stream) (void)hipStreamDestroy(rk.up_stream);
         if (rk.stream) (void)hipStreamDestroy(rk.stream);
     }
     // (librccl stays loaded: unloading a library with live GPU state is not worth the risk)
@@ -398,8 +460,7 @@ extern "C" int ipx_group_destroy(ipx_group *g)
 extern "C" int ipx_group_set_params(ipx_group *g, const ipx_params *p)
 {
     IPX_REQUIRE(g && p, "null pointer");
-    g->p = *p;
-    for (Rank &rk : g->ranks) IPX_TRY(ipx_set_params(rk.ctx, p));
+    g->p = *p;                                             // taken by the chunks submitted from now on
     return IPX_OK;
 }
 
@@ -411,14 +472,19 @@ extern "C" int ipx_group_info(const ipx_group *g, int *ndev, int *transport)
     return IPX_OK;
 }
 
-extern "C" int ipx_group_detect_chunk(ipx_group *g, const uint8_t *frames_host, int n, int H, int W,
-                                      const double *pow2_table_host, int tdim,
-                                      float *flows_host, uint8_t *keep_host, int64_t *counts_host, int64_t *cluster_host)
+extern "C" int ipx_group_submit(ipx_group *g, const uint8_t *frames_host, int n, int H, int W,
+                                const double *pow2_table_host, int tdim,
+                                float *flows_host, uint8_t *keep_host, int64_t *counts_host, int64_t *cluster_host)
 {
     IPX_REQUIRE(g && frames_host && pow2_table_host && flows_host && keep_host && counts_host && cluster_host, "null pointer");
     IPX_REQUIRE(n >= 2 && H >= 2 && W >= 2 && tdim >= 1, "bad sizes (at least 2 frames of at least 2x2)");
     IPX_REQUIRE(n / g->nd + 1 + 2 * (g->p.sliding_window_radius > 1 ? g->p.sliding_window_radius : 1) <= 65535, "at most 65535 frames (halo included) per rank");
     IPX_REQUIRE(g->p.sliding_window_radius >= 1, "sliding_window_radius must be >= 1");
+    IPX_REQUIRE(g->inflight.size() < 2, "two chunks are in flight already: ipx_group_wait first");
+    if (g->broken) {
+        ipx_set_error("ipx_group_submit: an earlier chunk abandoned an RCCL collective; the group cannot be used any more");
+        return IPX_ERR_HIP;
+    }
     const int edge = g->p.consecutive_threshold - 1 > 0 ? g->p.consecutive_threshold - 1 : 0;
     const int least = edge > 1 ? edge : 1;
     if (n / g->nd < least) {
@@ -426,16 +492,73 @@ extern "C" int ipx_group_detect_chunk(ipx_group *g, const uint8_t *frames_host, 
                       n, g->nd, least);
         return IPX_ERR_ARG;
     }
-    Call c = {g, frames_host, n, H, W, pow2_table_host, tdim, flows_host, keep_host, counts_host, cluster_host};
-    g->failed.store(false);
-    std::vector<std::thread> th;
-    for (int r = 1; r < g->nd; ++r) th.emplace_back(rank_thread, &c, r);
-    rank_thread(&c, 0);                                    // rank 0 runs on the caller's thread
-    for (std::thread &t : th) t.join();
-    for (int r = 0; r < g->nd; ++r)
-        if (g->ranks[r].status != IPX_OK) {
-            ipx_set_error("group rank %d (device %d): %s", r, g->ranks[r].device, g->ranks[r].error);
-            return g->ranks[r].status;
+    // ---- the upload: every rank's frame range + halo into the frame buffer the chunk before does not use, on the rank's
+    // side stream, now -- under whatever the ranks are computing.  (The chunk that used this buffer last has been waited
+    // for: at most two are in flight.)  Pageable host memory makes these copies synchronous: ipx_host_register it.
+    const int buf = (int)(g->submitted & 1);
+    const size_t P = (size_t)H * W;
+    const int radius = g->p.sliding_window_radius > 1 ? g->p.sliding_window_radius : 1;
+    int caller_device = -1;
+    (void)hipGetDevice(&caller_device);
+    int status = IPX_OK;
+    for (int r = 0; r < g->nd && status == IPX_OK; ++r) {
+        Rank &rk = g->ranks[r];
+        int a, b;
+        shard_range(n, r, g->nd, a, b);
+        const int lo = a - radius > 0 ? a - radius : 0, hi = b + radius < n ? b + radius : n;
+        void *ext = nullptr;
+        hipError_t e = hipSetDevice(rk.device);
+        if (e == hipSuccess) {
+            status = ipx_scratch(rk.ctx, buf ? GS_FRAMES_B : GS_FRAMES, (size_t)(hi - lo) * P, &ext);
+            if (status != IPX_OK) break;
+            rk.ext[buf] = (uint8_t *)ext;
+            e = hipMemcpyAsync(ext, frames_host + (size_t)lo * P, (size_t)(hi - lo) * P, hipMemcpyHostToDevice, rk.up_stream);
         }
+        if (e == hipSuccess) e = hipEventRecord(rk.ev_up[buf], rk.up_stream);
+        if (e != hipSuccess) { ipx_set_error("ipx_group_submit: upload for rank %d failed: %s", r, hipGetErrorString(e)); status = IPX_ERR_HIP; }
+    }
+    if (caller_device >= 0) (void)hipSetDevice(caller_device);
+    if (status != IPX_OK) {
+        for (Rank &rk : g->ranks) { (void)hipSetDevice(rk.device); (void)hipStreamSynchronize(rk.up_stream); }
+        if (caller_device >= 0) (void)hipSetDevice(caller_device);
+        return status;
+    }
+    Call *c = new Call();
+    c->g = g; c->frames = frames_host; c->n = n; c->H = H; c->W = W;
+    c->tab.assign(pow2_table_host, pow2_table_host + (size_t)tdim * tdim); c->tdim = tdim;
+    c->flows = flows_host; c->keep = keep_host; c->counts = counts_host; c->cluster = cluster_host;
+    c->p = g->p; c->buf = buf; c->seq = g->submitted++;
+    c->ranks_left.store(g->nd);
+    c->status.assign(g->nd, IPX_OK);
+    c->error.assign(g->nd, std::string());
+    g->inflight.push_back(c);
+    for (int r = 0; r < g->nd; ++r) c->th.emplace_back(rank_thread, c, r);
     return IPX_OK;
+}
+
+extern "C" int ipx_group_wait(ipx_group *g)
+{
+    IPX_REQUIRE(g, "null pointer");
+    IPX_REQUIRE(!g->inflight.empty(), "no chunk in flight");
+    Call *c = g->inflight.front();
+    g->inflight.pop_front();
+    for (std::thread &t : c->th) t.join();
+    int status = IPX_OK;
+    for (int r = 0; r < g->nd && status == IPX_OK; ++r)
+        if (c->status[r] != IPX_OK) {
+            ipx_set_error("group rank %d (device %d): %s", r, g->ranks[r].device, c->error[r].c_str());
+            status = c->status[r];
+        }
+    delete c;
+    return status;
+}
+
+extern "C" int ipx_group_detect_chunk(ipx_group *g, const uint8_t *frames_host, int n, int H, int W,
+                                      const double *pow2_table_host, int tdim,
+                                      float *flows_host, uint8_t *keep_host, int64_t *counts_host, int64_t *cluster_host)
+{
+    IPX_REQUIRE(g, "null pointer");
+    IPX_REQUIRE(g->inflight.empty(), "chunks submitted with ipx_group_submit are still in flight: ipx_group_wait first");
+    IPX_TRY(ipx_group_submit(g, frames_host, n, H, W, pow2_table_host, tdim, flows_host, keep_host, counts_host, cluster_host));
+    return ipx_group_wait(g);
 }

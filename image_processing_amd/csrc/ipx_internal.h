@@ -17,7 +17,7 @@ enum ipx_slot {
     SLOT_FLOW_UV,        // flow.hip: flow fields (two levels, ping-pong)
     SLOT_FLOW_RED,       // flow.hip: partial sums of the magnitude reduction
     WS_RAW, WS_BRIGHT, WS_PERS, WS_STATIC, WS_FINAL, WS_MAPS, WS_COUNTS,   // chunk.hip (and the ranks of group.hip)
-    GS_FRAMES, GS_MISC, GS_EDGES, GS_PERS_ALL, GS_MAPS_ALL,                // group.hip: a rank's frames, small arrays, exchange areas
+    GS_FRAMES, GS_FRAMES_B, GS_MISC, GS_EDGES, GS_PERS_ALL, GS_MAPS_ALL,   // group.hip: a rank's frames (two buffers: the next chunk uploads under this one), small arrays, exchange areas
     SLOT_COUNT
 };
 
@@ -55,6 +55,18 @@ struct ipx_ctx {
     unsigned fi_spin_limit;     // flow_iter_kernel: polls of the consumers' hand-off before it is given up (error word)
     int flow_ran;               // the flow stage has used SLOT_FLOW_RED (whose first word is its error word)
     ipx_prof prof;
+};
+
+// roctx ranges: host-side markers around the enqueue of each stage of the path, so that a
+// rocprofv3 --marker-trace run carries the stage names beside the kernel trace.  libroctx64.so is resolved with
+// dlopen at first use (no link-time dependency); without it, or with IPX_ROCTX=0, the calls do nothing.
+void ipx_range_push(const char *name);
+void ipx_range_pop(void);
+struct ipx_range {
+    explicit ipx_range(const char *name) { ipx_range_push(name); }
+    ~ipx_range() { ipx_range_pop(); }
+    ipx_range(const ipx_range &) = delete;
+    ipx_range &operator=(const ipx_range &) = delete;
 };
 
 void ipx_prof_begin(ipx_ctx *ctx, int kid, double bytes);

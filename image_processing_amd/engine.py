@@ -90,6 +90,7 @@ class Engine:
         assert dev.is_contiguous() and dev.numel() == a.size
         pinned = False
         if register:
+            # (a refusal -- memory that is pinned already, or that cannot be pinned -- only means a staged copy)
             pinned = lib.ipx_host_register(C.c_void_p(a.ctypes.data), a.nbytes) == 0
         self._enter()
         check(lib.ipx_upload_frames(self._ctx, C.c_void_p(a.ctypes.data), a.nbytes, _ptr(dev)))
@@ -140,6 +141,15 @@ class Engine:
         self._enter()
         check(lib.ipx_bgr2gray(self._ctx, _ptr(bgr), gray.numel(), _ptr(gray)))
         return gray
+
+    def unpack_dib(self, raw, rec_bytes, n, H, W, bits_per_pixel, stride, bottom_up, out=None):
+        """ipx_unpack_dib: ``raw`` = device bytes of n AVI frame records (frame i at i * rec_bytes) -> (n,H,W) uint8 frames."""
+        assert raw.is_cuda and raw.dtype == torch.uint8 and raw.is_contiguous()
+        assert raw.numel() >= (n - 1) * rec_bytes + stride * H
+        frames = torch.empty((n, H, W), dtype=torch.uint8, device=self.device) if out is None else out
+        self._enter()
+        check(lib.ipx_unpack_dib(self._ctx, _ptr(raw), rec_bytes, n, H, W, bits_per_pixel, stride, int(bool(bottom_up)), _ptr(frames)))
+        return frames
 
     def flow_metric(self, frames, prev_frame=None, want_keep=True):
         n, H, W = self._chk_frames(frames)
@@ -330,6 +340,7 @@ class Group:
         check(lib.ipx_group_info(self._g, C.byref(nd), C.byref(tr)))
         self.devices, self.transport = devs, {v: k for k, v in self.TRANSPORTS.items()}[tr.value]
         self.params = None
+        self._pending = []                                 # chunks in flight (their host arrays stay alive here)
         self.set_params(params)
 
     def set_params(self, params=None):
@@ -346,8 +357,9 @@ class Group:
 
     def close(self):
         if self._g:
-            lib.ipx_group_destroy(self._g)
+            lib.ipx_group_destroy(self._g)                 # waits for whatever is still in flight
             self._g = C.c_void_p()
+            self._pending = []
 
     def __del__(self):
         try:
@@ -355,36 +367,72 @@ class Group:
         except Exception:
             pass
 
-    def detect_chunk(self, frames):
-        """frames: (n,H,W) uint8 numpy array in host memory -> the dict of Engine.detect_chunk (without masks)."""
+    def submit(self, frames):
+        """ipx_group_submit: start a chunk ((n,H,W) uint8 numpy array in HOST memory; pinned memory -- a torch pinned
+        tensor's ``.numpy()``, or an array registered with ipx_host_register -- lets the upload run under the chunk before);
+        returns a handle for ``wait``.  At most two chunks in flight, waited for in the order submitted."""
         a = np.ascontiguousarray(frames, dtype=np.uint8)
         n, H, W = a.shape
-        flows = np.empty(n, dtype=np.float32)
-        keep = np.empty(n, dtype=np.uint8)
-        counts = np.empty((n, 5), dtype=np.int64)
-        cluster = np.empty((n, 3), dtype=np.int64)
-        tab = np.ascontiguousarray(self._pow2, dtype=np.float64)
+        h = dict(frames=a, n_pixels=H * W, flows=np.empty(n, dtype=np.float32), keep=np.empty(n, dtype=np.uint8),
+                 counts=np.empty((n, 5), dtype=np.int64), cluster=np.empty((n, 3), dtype=np.int64),
+                 tab=np.ascontiguousarray(self._pow2, dtype=np.float64))
         vp = lambda x: C.c_void_p(x.ctypes.data)
-        check(lib.ipx_group_detect_chunk(self._g, vp(a), n, H, W, vp(tab), self._pow2_dim, vp(flows), vp(keep), vp(counts),
-                                         vp(cluster)))
-        total, cc, cs, cb = hostmath.chunk_results(keep, counts, cluster, H * W)
+        check(lib.ipx_group_submit(self._g, vp(a), n, H, W, vp(h["tab"]), self._pow2_dim, vp(h["flows"]), vp(h["keep"]),
+                                   vp(h["counts"]), vp(h["cluster"])))
+        self._pending.append(h)
+        return h
+
+    def wait(self, handle=None):
+        """ipx_group_wait for the oldest chunk in flight (``handle``, if given, must be that chunk's) -> the dict of
+        Engine.detect_chunk (without masks)."""
+        if not self._pending:
+            raise RuntimeError("no chunk in flight")
+        h = self._pending.pop(0)
+        if handle is not None and handle is not h:
+            self._pending.insert(0, h)
+            raise RuntimeError("chunks are waited for in the order they were submitted")
+        check(lib.ipx_group_wait(self._g))
+        total, cc, cs, cb = hostmath.chunk_results(h["keep"], h["counts"], h["cluster"], h["n_pixels"])
         return dict(total_counts=total, cluster_counts=cc, avg_sizes=cs, avg_brightnesses=cb,
-                    flows=_check_flows(flows.astype(np.float64)), keep=keep, counts=counts, cluster=cluster)
+                    flows=_check_flows(h["flows"].astype(np.float64)), keep=h["keep"], counts=h["counts"], cluster=h["cluster"])
+
+    def detect_chunk(self, frames):
+        """frames: (n,H,W) uint8 numpy array in host memory -> the dict of Engine.detect_chunk (without masks)."""
+        return self.wait(self.submit(frames))
 
 
 class _Upload:
     """A pending ipx_upload_frames: ``tensor`` may be handed to any engine method right away (they wait on the
-    device); ``release()`` (after a synchronisation point of the consumer) unpins the host array."""
+    device); ``release()`` waits for the copy and unpins the host array.  The handle keeps the host array alive;
+    dropping it without ``release()`` (or leaving a ``with`` block) releases it the same way, so the array is never
+    freed while it is registered or while the copy may still read it."""
 
     def __init__(self, eng, tensor, host, pinned):
         self.eng, self.tensor, self.host, self.pinned = eng, tensor, host, pinned
 
     def release(self):
-        if self.pinned:
-            self.eng.synchronize()
-            lib.ipx_host_unregister(C.c_void_p(self.host.ctypes.data))
-            self.pinned = False
-        self.host = None
+        if self.host is None:
+            return
+        try:
+            self.eng.synchronize()                       # the side-stream copy has read the array
+        finally:
+            if self.pinned:
+                lib.ipx_host_unregister(C.c_void_p(self.host.ctypes.data))
+                self.pinned = False
+            self.host = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.release()
+        return False
+
+    def __del__(self):
+        try:
+            self.release()
+        except Exception:                                # noqa: BLE001 - interpreter shutdown, context already gone
+            pass
 
 
 def _check_flows(flows):

@@ -140,7 +140,8 @@ def _worker(slot, device, jobs, main_kwargs, per_video_output, conn):
             t0 = time.perf_counter()
             res = ip.main(video, **kw)
             torch.cuda.synchronize()
-            res = {k: (v.tolist() if hasattr(v, "tolist") else list(v)) for k, v in res.items()}
+            res = {k: (v.tolist() if hasattr(v, "tolist") else (list(v) if isinstance(v, (list, tuple)) else v))
+                   for k, v in res.items()}
             conn.send(("ok", index, res, time.perf_counter() - t0, int(device)))
         conn.send(("done", slot, None, 0.0, int(device)))
     except BaseException:                               # noqa: BLE001

@@ -101,6 +101,14 @@ int ipx_upload_frames(ipx_ctx *ctx, const uint8_t *host_frames, size_t bytes, ui
 
 /* ---- a1: load_video_frames' grey conversion, ip.py:78-79 (cv2.cvtColor BGR2GRAY) --------- */
 int ipx_bgr2gray(ipx_ctx *ctx, const uint8_t *bgr, size_t npix, uint8_t *gray);
+/* The same step for frames still in the layout an uncompressed AVI stores them in (what cv2.VideoCapture.read +
+ * cvtColor do on the CPU in ip.py:62-85): n device-resident DIBs, frame i at raw + i * rec_bytes, rows of `stride`
+ * bytes (padded to 4), bottom-up when bottom_up != 0, 8 bits per pixel (grey-ramp palette: the indices are the grey
+ * levels) or 24 (BGR, converted with the luma of ipx_bgr2gray) -> frames uint8 [n][H][W], top-down.  Lets a decoder
+ * thread read a whole chunk of the file with a few large reads into pinned memory and leave the row flip, the
+ * padding and the colour conversion to the GPU. */
+int ipx_unpack_dib(ipx_ctx *ctx, const uint8_t *raw, size_t rec_bytes, int n, int H, int W, int bits_per_pixel,
+                   int stride, int bottom_up, uint8_t *frames);
 
 /* ---- a3: compute_optical_flow_metric, ip.py:852-873 --------------------------------------
  * flows[0] = 0 (or the metric against prev_frame when given: the left halo of a frame-range
@@ -122,7 +130,9 @@ int ipx_flow_status(ipx_ctx *ctx, int *raised, int clear);     /* synchronises t
  * partner waves (default 2^27, ~10 s); 0 forces the failure path described above. */
 int ipx_debug_fi_spin_limit(ipx_ctx *ctx, unsigned limit);
 /* One Farneback pair on float32 images, full flow field (H,W,2) out: unit parity of
- * cv2.calcOpticalFlowFarneback(prev,next,None,0.5,3,15,3,5,2.0,0), ip.py:858-867. */
+ * cv2.calcOpticalFlowFarneback(prev,next,None,0.5,3,15,3,5,2.0,0), ip.py:858-867.
+ * The field of a call during which the stage's error word was raised (see ipx_flow_metric) is
+ * not valid: ipx_synchronize / ipx_flow_status report the condition, the field itself carries no mark. */
 int ipx_farneback_pair(ipx_ctx *ctx, const float *prev, const float *next, int H, int W, float *flow);
 
 /* ---- a4/a5: compute_background + _find_background, ip.py:183-252 -------------------------- */
@@ -238,8 +248,15 @@ int ipx_detect_chunk(ipx_ctx *ctx, const uint8_t *frames, int n, int H, int W,
  * is loaded at run time; devices must be distinct; a group of one still runs its collectives), IPX_GROUP_PEER =
  * hipMemcpyPeerAsync between the ranks' buffers (a device may be listed more than once), IPX_GROUP_AUTO = RCCL
  * for two or more distinct devices when librccl loads, else peer copies.  devices == NULL means 0 .. ndev-1.
- * One ipx_group_detect_chunk at a time per group (the call is synchronous; use one group per calling thread).  When a
- * rank fails, all ranks stop at their next meeting point and the call returns that rank's status and message. */
+ * One calling thread per group.  When a rank fails, all ranks stop at their next meeting point and the call returns
+ * that rank's status and message (over RCCL the communicator is then abandoned, ncclCommAbort, and the group takes
+ * no further chunks).
+ * ipx_group_submit / ipx_group_wait: the same chunk call in two halves, so that two chunks can be in flight.  submit
+ * starts the upload of every rank's frames at once (side stream, second frame buffer: it runs under the chunk the
+ * ranks are still computing) and returns; wait returns when the OLDEST submitted chunk is complete, with its status.
+ * At most two chunks in flight; the host arrays of a chunk (frames in, results out) must stay valid and untouched
+ * until its wait returns; frames in pageable memory make the upload synchronous (pin them: ipx_host_register).
+ * ipx_group_set_params applies to the chunks submitted after it.  ipx_group_detect_chunk = submit + wait. */
 typedef struct ipx_group ipx_group;
 #define IPX_GROUP_AUTO 0
 #define IPX_GROUP_PEER 1
@@ -251,6 +268,10 @@ int ipx_group_info(const ipx_group *g, int *ndev, int *transport);
 int ipx_group_detect_chunk(ipx_group *g, const uint8_t *frames_host, int n, int H, int W,
                            const double *pow2_table_host, int tdim,
                            float *flows_host, uint8_t *keep_host, int64_t *counts_host, int64_t *cluster_host);
+int ipx_group_submit(ipx_group *g, const uint8_t *frames_host, int n, int H, int W,
+                     const double *pow2_table_host, int tdim,
+                     float *flows_host, uint8_t *keep_host, int64_t *counts_host, int64_t *cluster_host);
+int ipx_group_wait(ipx_group *g);
 
 /* ---- helpers: host<->device packing used by the Python stage wrappers ----------------------- */
 int ipx_pack_mask(ipx_ctx *ctx, const uint8_t *mask, int count, int H, int W, uint64_t *bits);

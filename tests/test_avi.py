@@ -144,3 +144,31 @@ def test_failed_open_leaves_nothing_open(tmp_path):
     import os
     os.remove(fn)                                           # (would fail on platforms that lock mapped files)
     assert not avi.VideoCapture(fn).isOpened()
+
+
+def test_record_layout_and_region_read(tmp_path):
+    """The chunk driver's raw path: frames [a, b) of a plain uncompressed AVI are one evenly spaced region of the file,
+    read with large positional reads; record i of the region holds frame a + i as a bottom-up DIB with padded rows."""
+    rng = np.random.default_rng(5)
+    for shape in ((9, 13), (8, 16), (5, 7, 3)):
+        frames = rng.integers(0, 256, (11,) + shape, dtype=np.uint8)
+        fn = str(tmp_path / ("r%d.avi" % len(shape)))
+        avi.write_avi(fn, list(frames), fps=10.0)
+        r = avi.AviReader(fn)
+        try:
+            assert r.record_layout(0, 12) is None and r.record_layout(3, 3) is None
+            for a, b in ((0, 11), (2, 7), (10, 11)):
+                off0, rec, nbytes = r.record_layout(a, b)
+                h, w = shape[:2]
+                stride = r.stride
+                assert stride % 4 == 0 and stride >= w * (3 if len(shape) == 3 else 1) and r.bottom_up
+                assert nbytes == (b - a - 1) * rec + stride * h and (b - a == 1 or rec == stride * h + 8)
+                buf = np.zeros(nbytes + 5, np.uint8)
+                r.read_region_into(off0, buf[:nbytes], threads=3, piece=64)
+                assert (buf[nbytes:] == 0).all()
+                for i in range(b - a):
+                    dib = buf[i * rec:i * rec + stride * h].reshape(h, stride)[::-1]
+                    got = dib[:, :w] if len(shape) == 2 else dib[:, :3 * w].reshape(h, w, 3)
+                    assert np.array_equal(got, frames[a + i])
+        finally:
+            r.close()

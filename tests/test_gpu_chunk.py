@@ -300,3 +300,53 @@ def test_upload_frames_side_stream_then_detect():
             assert bool((up.tensor.cpu() == torch.from_numpy(frames)).all())
     finally:
         eng.close()
+
+
+def test_flow_above_25_megapixels(eng):
+    """a SHORT call on frames above 25.2 M pixels.  The dead positions of flow_iter_kernel's loads used to
+    resolve, for the 4-byte coefficient plane, to an offset inside such a frame's resource and from there (scalar offset
+    added) to up to 0.9 GB past the end of a small batch's allocation.  One pair (the least scratch, the case with the
+    least slack behind the arena) of 6144 x 4320 frames: the field and the metric must equal the oracle's as at any other
+    size, and the stage's error word stays clear."""
+    from oracle import cref
+    h, w = 4320, 6144                                   # 26.5 M pixels
+    a, b = _moving_pair(5, h, w, 3.0)
+    ref = cref.farneback(a.astype(np.float32), b.astype(np.float32))
+    got = eng.farneback_pair(eng.to_device(a.astype(np.float32)), eng.to_device(b.astype(np.float32))).cpu().numpy()
+    eng.synchronize()
+    assert not eng.flow_status()
+    err = np.abs(got.astype(np.float64) - ref.astype(np.float64))
+    scale = max(1.0, float(np.abs(ref).max()))
+    assert np.isfinite(got).all() and err.max() <= 1e-6 * scale, "max |dflow| = %g (flow scale %g)" % (err.max(), scale)
+    assert int((err > 1e-12 * scale).sum()) <= 1e-5 * err.size
+    mref = float(np.mean(cref.flow_magnitude(ref)))
+    del got, err
+    flows, keep = eng.flow_metric(eng.to_device(np.stack([a, b])))
+    eng.synchronize()
+    assert not eng.flow_status()
+    f = flows.cpu().numpy()
+    assert f[0] == 0.0 and abs(f[1] - mref) <= FLOW_RTOL * mref and keep.cpu().numpy().tolist() == [1, 0]
+    import torch
+    torch.cuda.empty_cache()
+
+
+def test_flow_error_word_survives_a_bigger_call(eng):
+    """the stage's error word is sticky until ipx_flow_status(..., clear) -- also when a later, larger call
+    makes the arena that holds it grow."""
+    import ctypes as C
+    from image_processing_amd import _ipx, synth
+    from image_processing_amd.engine import Engine
+    e2 = Engine(0)
+    try:
+        small = e2.to_device(synth.chunk_numpy(3, 3, 40, 56, hot=4.0))
+        _ipx.check(_ipx.lib.ipx_debug_fi_spin_limit(e2._ctx, 0))       # every hand-off gives up at once
+        flows, keep = e2.flow_metric(small)
+        assert np.isnan(flows.cpu().numpy()[1:]).all() and keep.cpu().numpy()[1:].sum() == 0
+        _ipx.check(_ipx.lib.ipx_debug_fi_spin_limit(e2._ctx, 1 << 27))
+        big = e2.to_device(synth.chunk_numpy(4, 40, 300, 420, hot=4.0))   # needs a larger reduction arena
+        e2.flow_metric(big)
+        assert e2.flow_status(clear=True)                                  # still raised after the regrow
+        flows, _ = e2.flow_metric(big)
+        assert not e2.flow_status() and np.isfinite(flows.cpu().numpy()).all()
+    finally:
+        e2.close()

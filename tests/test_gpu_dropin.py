@@ -228,6 +228,13 @@ def test_main_on_avi(ip, tmp_path):
     fn2 = str(tmp_path / "clip_bgr.avi")
     avi.write_avi(fn2, [np.repeat(f[:, :, None], 3, axis=2) for f in frames[:4]], fps=4.0)
     assert np.array_equal(np.stack(ip.load_video_frames(fn2)), frames[:4])
+    # ... and the chunk driver, which uploads such a file's bytes as stored and converts on the GPU (ipx_unpack_dib),
+    # returns what it returns for the greyscale file
+    fn3 = str(tmp_path / "clip_bgr_all.avi")
+    avi.write_avi(fn3, [np.repeat(f[:, :, None], 3, axis=2) for f in frames], fps=4.0)
+    res3 = ip.main(fn3, average_time=1.0, max_chunks=None, step_size=7)
+    for key in ("averages_counts", "averages_clusters", "averages_size", "averages_brightness", "times"):
+        assert _eq_nan(res[key], res3[key]), key
 
 
 def test_main_streams_chunks_like_the_sequential_driver(ip, tmp_path, monkeypatch):
@@ -276,8 +283,10 @@ def test_main_checkpoints_and_resumes(ip, tmp_path, monkeypatch):
                             (loaded.append((frames_start, frames_end)), orig(f, frames_start, frames_end, grayscale))[1])
         again = ip.main(fn, max_chunks=None, step_size=5, checkpoint_folder=ck)
     assert loaded == [(10, 15)]
-    for k in first:
+    for k in ("averages_counts", "averages_clusters", "averages_size", "averages_brightness", "times"):
         assert _eq_nan(first[k], again[k]), k
+    # (not in the reference) the margin of the motion test over the chunks computed in the run: all four, then the one
+    assert first["min_flow_margin"] > 0 and again["min_flow_margin"] >= first["min_flow_margin"]
 
 
 def test_randomised_labelling_stages_sweep():

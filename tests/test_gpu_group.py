@@ -74,6 +74,41 @@ def test_group_auto_and_errors():
     g.close()
 
 
+@pytest.mark.parametrize("world,transport", [(1, "peer"), (3, "peer"), (1, "rccl")])
+def test_group_two_chunks_in_flight(world, transport):
+    """ipx_group_submit / ipx_group_wait: chunk k+1 is submitted (its frames uploaded on the ranks' side streams into
+    their second frame buffer) while chunk k is being computed; every chunk must equal its own single-context result,
+    also when geometry, length and PARAMETERS change from one chunk to the next, from pinned and from pageable memory."""
+    import torch
+    from image_processing_amd import _ipx
+    from image_processing_amd.engine import Engine, Group
+    pa, pb = dict(consecutive_threshold=3, sliding_window_radius=2), dict(consecutive_threshold=2, static_threshold=20)
+    chunks = [(_frames(11, 18, 90, 150), pa), (_frames(12, 18, 90, 150), pa), (_frames(13, 23, 64, 100), pb),
+              (_frames(14, 12, 90, 150), pb), (_frames(15, 18, 90, 150), pa)]
+    refs = [Engine(0, p).detect_chunk(fr) for fr, p in chunks]
+    g = Group([0] * world, pa, transport=transport)
+    with pytest.raises(RuntimeError):
+        g.wait()                                           # nothing in flight
+    pinned = [torch.from_numpy(fr).pin_memory() for fr, _ in chunks]
+    pending = []
+    for k, (fr, p) in enumerate(chunks):
+        g.set_params(p)                                    # applies to the chunks submitted from now on
+        pending.append((k, g.submit(pinned[k].numpy() if k % 2 == 0 else fr)))
+        if len(pending) == 2:
+            if k == 1:
+                with pytest.raises(_ipx.IpxError, match="two chunks are in flight"):
+                    g.submit(fr)
+                with pytest.raises(RuntimeError, match="in the order"):
+                    g.wait(pending[1][1])
+            j, h = pending.pop(0)
+            _same(g.wait(h), refs[j])
+    j, h = pending.pop(0)
+    _same(g.wait(h), refs[j])
+    _same(g.detect_chunk(chunks[0][0]), Engine(0, chunks[-1][1]).detect_chunk(chunks[0][0]))   # the synchronous form after it
+    g.submit(chunks[1][0])
+    g.close()                                              # closing with a chunk in flight waits for it
+
+
 def test_group_full_size_shards():
     """1080p, 96 frames over 4 ranks on device 0: the sizes of the real workload (one strip per 114 columns, 128 x 64
     detect tiles, 17 + 9 words per row) through the group path."""

@@ -335,3 +335,28 @@ def test_bgr2gray(eng):
     assert np.array_equal(got, cref.bgr2gray_u8(bgr))
     grey = np.repeat(rng.integers(0, 256, (5, 7, 1)).astype(np.uint8), 3, axis=2)
     assert np.array_equal(eng.bgr2gray(eng.to_device(grey)).cpu().numpy(), grey[..., 0])   # identity on grey-coded video
+
+
+@pytest.mark.parametrize("shape", [(9, 13), (8, 16), (31, 100), (5, 7, 3), (12, 64, 3)])
+def test_unpack_dib_equals_the_avi_reader(eng, shape, tmp_path):
+    """ipx_unpack_dib (the chunk driver's input step on the GPU: rows turned over, padding dropped, BGR -> grey) against
+    the frames the AVI reader + luma restatement return, for any width (dword and byte paths), from frame ranges."""
+    import torch
+    from image_processing_amd import avi
+    from oracle import cref
+    rng = np.random.default_rng(sum(shape))
+    frames = rng.integers(0, 256, (7,) + shape, dtype=np.uint8)
+    fn = str(tmp_path / "d.avi")
+    avi.write_avi(fn, list(frames), fps=5.0)
+    r = avi.AviReader(fn)
+    try:
+        for a, b in ((0, 7), (2, 5), (6, 7)):
+            off0, rec, nbytes = r.record_layout(a, b)
+            buf = np.empty(nbytes, np.uint8)
+            r.read_region_into(off0, buf, threads=2, piece=128)
+            got = eng.unpack_dib(torch.from_numpy(buf).to(eng.device), rec, b - a, shape[0], shape[1], r.bpp, r.stride,
+                                 r.bottom_up).cpu().numpy()
+            exp = frames[a:b] if len(shape) == 2 else np.stack([cref.bgr2gray_u8(f) for f in frames[a:b]])
+            assert np.array_equal(got, exp)
+    finally:
+        r.close()
