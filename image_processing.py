@@ -750,9 +750,10 @@ class _RawChunk:
     a pinned staging buffer.  The row flip, the padding and (24-bit streams) the luma conversion are left to the GPU
     (ipx_unpack_dib), so the decode thread moves every byte exactly once, at memcpy speed."""
 
-    def __init__(self, slot, nbytes, n, rec, height, width, bpp, stride, bottom_up):
+    def __init__(self, slot, nbytes, n, rec, height, width, bpp, stride, bottom_up, staged=None, uploaded=None):
         self.slot, self.nbytes, self.n, self.rec = slot, nbytes, n, rec
         self.height, self.width, self.bpp, self.stride, self.bottom_up = height, width, bpp, stride, bottom_up
+        self.staged, self.uploaded = staged, uploaded     # the same bytes in HBM and the event of their arrival
 
     def __len__(self):
         return self.n
@@ -801,6 +802,9 @@ class _StagingRing:
 
 _RING_POOL = []
 _RING_LOCK = _threading.Lock()
+#: set to a list to have the chunk drivers append (chunk index, seconds when taken up, seconds when delivered) to it
+#: (time.perf_counter); bench.py reads the steady-state rate of the input side from it
+_TIMELINE = None
 
 
 def _ring_acquire():
@@ -818,11 +822,18 @@ def _ring_release(ring):
             _RING_POOL.append(ring)
 
 
-def _load_chunk_raw_avi(video_filename, start, end, ring):
+_UPLOAD_PIECE = 64 << 20
+_UPLOAD_IN_DECODER = os.environ.get("IPX_UPLOAD_IN_DECODER", "1") != "0"   # (A/B switch: tools/avi_modes.py)
+
+
+def _load_chunk_raw_avi(video_filename, start, end, ring, device=None):
     """The decode thread's short cut for uncompressed AVI files (what the benchmarks and the camera pipeline store) read
     by our own reader, with load_video_frames not replaced by the caller: the chunk's bytes go from the page cache into
-    pinned memory as they are stored.  Returns None when any of that does not hold (cv2 importable, compressed or
-    palettised-colour stream, frames not evenly spaced in the file)."""
+    pinned memory as they are stored, in 64 MB pieces read by a few threads, and every piece is sent on to HBM (this
+    thread's copy stream on ``device``) as soon as it and the pieces before it are there -- the upload runs under the
+    reads instead of after them, which is what a video's FIRST chunk, that nothing else overlaps, is waiting for.
+    Returns None when any of that does not hold (cv2 importable, compressed or palettised-colour stream, frames not
+    evenly spaced in the file)."""
     if ring is None or cv2 is not None or not _pristine("load_video_frames"):
         return None
     try:
@@ -841,9 +852,35 @@ def _load_chunk_raw_avi(video_filename, start, end, ring):
             return None
         off0, rec, nbytes = layout
         slot = ring.take(nbytes)
-        reader.read_region_into(off0, slot["host"].numpy()[:nbytes], threads=_DECODE_THREADS)
+        host = slot["host"][:nbytes]
+        if device is None:
+            device = torch.cuda.current_device()
+        dev = torch.device("cuda", int(device))
+        torch.cuda.set_device(dev)                       # (this is the decode thread: its current device is its own)
+        copy_stream = getattr(_TLS, "decode_stream", None)
+        if copy_stream is None or copy_stream.device != dev:
+            copy_stream = _TLS.decode_stream = torch.cuda.Stream(dev)
+        # (device memory comes back to torch's allocator only when a chunk's results have arrived -- _submit_chunk's
+        # keep-alive list -- so a block handed out here is not in use by anything still queued on the GPU)
+        staged = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        view = host.numpy()
+        spans = [(a, min(nbytes, a + _UPLOAD_PIECE)) for a in range(0, nbytes, _UPLOAD_PIECE)]
+        from concurrent.futures import ThreadPoolExecutor
+        if not _UPLOAD_IN_DECODER:
+            reader.read_region_into(off0, view, threads=_DECODE_THREADS)
+            return _RawChunk(slot, nbytes, end - start, rec, reader.height, reader.width, reader.bpp, reader.stride,
+                             reader.bottom_up)
+        with ThreadPoolExecutor(max_workers=_DECODE_THREADS) as pool:
+            reads = [pool.submit(reader.read_region_into, off0 + a, view[a:b], 1) for a, b in spans]
+            with torch.cuda.stream(copy_stream):
+                for (a, b), done in zip(spans, reads):
+                    done.result()
+                    staged[a:b].copy_(host[a:b], non_blocking=True)
+                uploaded = torch.cuda.Event()
+                uploaded.record(copy_stream)
+        slot["busy"] = uploaded                           # the ring hands this buffer out again only after the copies
         return _RawChunk(slot, nbytes, end - start, rec, reader.height, reader.width, reader.bpp, reader.stride,
-                         reader.bottom_up)
+                         reader.bottom_up, staged, uploaded)
     finally:
         reader.close()
 
@@ -877,12 +914,12 @@ def _load_chunk_gray_avi(video_filename, start, end):
         reader.close()
 
 
-def _load_chunk(video_filename, start, end, ring=None):
+def _load_chunk(video_filename, start, end, ring=None, device=None):
     """Decode frames [start, end).  With a staging ring (the asynchronous chunk driver): a _RawChunk when the file allows
     it.  Otherwise (frames, pinned): the frames through the module's load_video_frames -- or the 8-bit AVI short cut --
     and, when they are plain greyscale uint8 frames of one size, the same frames stacked in pinned host memory for the
     asynchronous upload."""
-    raw = _load_chunk_raw_avi(video_filename, start, end, ring)
+    raw = _load_chunk_raw_avi(video_filename, start, end, ring, device)
     if raw is not None:
         return raw
     fast = _load_chunk_gray_avi(video_filename, start, end)
@@ -922,14 +959,17 @@ def _submit_chunk(chunk, idx, kw):
         copy_stream = getattr(_TLS, "copy_stream", None)
         if copy_stream is None or copy_stream.device != eng.device:
             copy_stream = _TLS.copy_stream = torch.cuda.Stream(eng.device)
-        src = raw.slot["host"][:raw.nbytes] if raw is not None else pinned
-        staged = torch.empty(src.shape, dtype=torch.uint8, device=eng.device)
-        with torch.cuda.stream(copy_stream):
-            staged.copy_(src, non_blocking=True)
-            uploaded = torch.cuda.Event()
-            uploaded.record(copy_stream)
-        if raw is not None:
-            raw.slot["busy"] = uploaded                  # the ring hands this buffer out again only after the copy
+        if raw is not None and raw.staged is not None and raw.staged.device == eng.device:
+            staged, uploaded = raw.staged, raw.uploaded   # the decode thread has sent the bytes on already
+        else:
+            src = raw.slot["host"][:raw.nbytes] if raw is not None else pinned
+            staged = torch.empty(src.shape, dtype=torch.uint8, device=eng.device)
+            with torch.cuda.stream(copy_stream):
+                staged.copy_(src, non_blocking=True)
+                uploaded = torch.cuda.Event()
+                uploaded.record(copy_stream)
+            if raw is not None:
+                raw.slot["busy"] = uploaded              # the ring hands this buffer out again only after the copy
         torch.cuda.current_stream(eng.device).wait_event(uploaded)
         if raw is not None:                              # rows the right way up, padding dropped, colour -> grey: on the GPU
             dev = eng.unpack_dib(staged, raw.rec, n, raw.height, raw.width, raw.bpp, raw.stride, raw.bottom_up)
@@ -992,22 +1032,36 @@ def _chunk_pipeline(video_filename, spans, order, kw, deliver, announce):
     if not order:
         return
     from concurrent.futures import ThreadPoolExecutor
+    import time
     ring = _ring_acquire()
+    timeline = _TIMELINE
+    try:
+        import torch
+        device = torch.cuda.current_device() if torch.cuda.is_available() else None
+    except ImportError:
+        device = None
+
+    def finish(done, idx, t_taken):
+        res = done()
+        if timeline is not None:
+            timeline.append((idx, t_taken, time.perf_counter()))
+        deliver(idx, res)
     try:
         with ThreadPoolExecutor(max_workers=1) as decoder:
-            nxt = decoder.submit(_load_chunk, video_filename, *spans[order[0]], ring)
-            pending = None                               # (completion, idx) of the chunk on the GPU
+            nxt = decoder.submit(_load_chunk, video_filename, *spans[order[0]], ring, device)
+            pending = None                               # (completion, idx, time taken up) of the chunk on the GPU
             for k, idx in enumerate(order):
                 chunk = nxt.result()
                 if k + 1 < len(order):
-                    nxt = decoder.submit(_load_chunk, video_filename, *spans[order[k + 1]], ring)
+                    nxt = decoder.submit(_load_chunk, video_filename, *spans[order[k + 1]], ring, device)
                 announce(idx)
+                t_taken = time.perf_counter()
                 done = _submit_chunk(chunk, idx, kw)
                 if pending is not None:
-                    deliver(pending[1], pending[0]())
-                pending = (done, idx)
+                    finish(*pending)
+                pending = (done, idx, t_taken)
             if pending is not None:
-                deliver(pending[1], pending[0]())
+                finish(*pending)
     finally:
         _ring_release(ring)
 

@@ -13,10 +13,20 @@ A kernel is cured by keeping a register allocated that the code does not use, so
 the allocation's last register: IPX_VGPR_PAD_SAFE() (ipx_internal.h; v62 -> a 64-register allocation whose last
 register the compiler never hands out), or IPX_VGPR_PAD(n) with n = the kernel's next_free_vgpr printed here.
 
-What the characterisation covers and what it does not (measured with tools/hwtest/seg_loop.hip only): the three
-opcodes below with a VGPR shift amount.  NOT tested: shift amounts held in SGPRs or given as constants, the
-64-bit shift folded into v_lshl_add_u64, other allocation granules than 8, and other opcodes that read a 64-bit
-pair next to the allocation's end.  The scan therefore guards the failure that was observed, not a class.
+What the characterisation covers (round 3: tools/hwtest/shift_forms.hip places each operand in the last registers of a
+16-VGPR allocation on purpose, 16 M lanes x 8 launches per form; output in profiles/r03m_shift64_forms.txt):
+
+    FAILS   v_lshlrev_b64 / v_lshrrev_b64 / v_ashrrev_i64 with the AMOUNT in the last allocated VGPR and the shifted value
+            NOT in a VGPR pair -- an inline constant (`v_lshlrev_b64 v[a:b], v15, -1`, the instruction of ccl.hip's
+            segment loop) or an SGPR pair.  The wrong results are shifts by the low bits of what the next allocation's
+            first register holds.  Wait states before the shift and loads in flight make no difference.
+    ok      the same three opcodes with the amount in the last VGPR and the value in a VGPR pair (anywhere);
+            the value or the destination pair in the last two VGPRs; the amount in an SGPR or a constant;
+            v_lshl_add_u64 with either 64-bit operand in the last pair; the amount in the last-but-one VGPR.
+
+The scan below flags every one of the three opcodes whose amount is the last allocated VGPR, whatever the other operand is:
+a superset of the failing forms.  Not measured: allocation granules other than 8 (the scan assumes 8), other opcodes that
+take a 32-bit VGPR operand beside a 64-bit constant or SGPR operand.
 """
 import os
 import re
@@ -96,6 +106,13 @@ def check_scratch(asm_text):
 # following write to its data registers (it does for a constant scalar offset), and on gfx950 the store then writes the new
 # contents (round 2: polyexp_kernel stored garbage in launches of more than about one workgroup per CU).  Such a store must be
 # followed by a wait state: ipx_buffer_store_b128 (csrc/flow_iter.h) issues `s_nop 1` behind it.
+# Round 3 (tools/hwtest/wide_store_forms.hip, profiles/r03i_wide_store_forms.txt), every form with no wait state / s_nop 0 / s_nop 1:
+#   buffer_store_dwordx2 (register soffset), global_store_dwordx2: no hazard;
+#   buffer_store_dwordx3 / x4 with a REGISTER soffset: wrong data at 16 workgroups per CU without a wait state (0.15 % of the
+#     dwords), none with one -- the 12-byte store is affected like the 16-byte one;
+#   buffer_store_dwordx3 / x4 with soffset 0 and global_store_dwordx3 / x4 (the forms the compiler covers): wrong data without
+#     a wait state (5.7 %), still 0.2 % with ONE, none with two (`s_nop 1`, what the compiler inserts for gfx940 and later).
+# The scan therefore asks for `s_nop 1` or longer behind the register-soffset forms, x3 included.
 WIDE_STORE = re.compile(r"\s*buffer_store_dwordx[34]\s+v\[\d+:\d+\],\s*\S+,\s*s\[\d+:\d+\],\s*(s\d+|m0|vcc_lo|vcc_hi|ttmp\d+)\b")
 
 
@@ -105,7 +122,11 @@ def check_wide_stores(asm_text):
     for name, body, _ in kernels_of(asm_text):
         code = [l for l in body if l.strip() and not l.strip().startswith(";")]
         for i, line in enumerate(code):
-            if WIDE_STORE.match(line) and not (i + 1 < len(code) and code[i + 1].strip().startswith("s_nop")):
+            if not WIDE_STORE.match(line):
+                continue
+            nxt = code[i + 1].strip() if i + 1 < len(code) else ""
+            m = re.match(r"s_nop\s+(\d+)", nxt)
+            if not (m and int(m.group(1)) >= 1):
                 bad.append((name, line.strip()))
     return bad
 

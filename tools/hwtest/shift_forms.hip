@@ -7,7 +7,8 @@
 // Every kernel keeps exactly 16 VGPRs allocated (v15 is named in the asm and nothing above it is used: the build prints
 // next_free_vgpr, which must be 16 for the placement to mean anything -- tools/hwtest/check_shift_forms.py asserts it from
 // the ISA), loads a 64-bit value and a shift amount per lane, applies ONE shift instruction of the form under test with the
-// operand in question in v15 / v[14:15], and stores the result.  The host compares with the shift done in C.  All addresses
+// operand in question in v15 / v[14:15] -- written by the instruction right before the shift (GAP 0) or two wait states
+// earlier (GAP 1) -- and stores the result.  The host compares with the shift done in C.  All addresses
 // are inside the arrays; nothing here can fault.  Many waves must be resident for the hazard to show (it reads a register of
 // the neighbouring allocation), hence the large grid and the repetitions.
 #include <hip/hip_runtime.h>
@@ -29,15 +30,28 @@ enum Form {
     F_LSHL_ADD_SRC_LAST,    // v_lshl_add_u64 d, v[14:15], 3, add    shifted source in the last pair
     F_LSHL_ADD_ADD_LAST,    // v_lshl_add_u64 d, src, 3, v[14:15]    addend in the last pair
     F_LSHL_DST_LAST,        // v_lshlrev_b64 v[14:15], amt, data     DESTINATION pair last
+    F_LSHL_CONST_DATA,      // v_lshlrev_b64 d, v15, -1              amount last, the shifted value an INLINE CONSTANT (seg_loop's instruction)
+    F_LSHR_CONST_DATA,      // v_lshrrev_b64 d, v15, -1
+    F_LSHL_CONST_DATA_NL,   // v_lshlrev_b64 d, v14, -1              the same with the amount in the last but one (control)
+    F_ASHR_CONST_DATA,      // v_ashrrev_i64 d, v15, -2
+    F_LSHL_SGPR_DATA,       // v_lshlrev_b64 d, v15, s[20:21]        the shifted value in an SGPR pair
     F_COUNT
 };
 static const char *const form_name[F_COUNT] = {
     "v_lshlrev_b64  amount = last VGPR", "v_lshrrev_b64  amount = last VGPR", "v_ashrrev_i64  amount = last VGPR",
     "v_lshlrev_b64  amount = last-but-one VGPR (control)", "v_lshlrev_b64  data pair = last two VGPRs",
     "v_lshlrev_b64  SGPR amount, data pair last", "v_lshlrev_b64  constant amount, data pair last",
-    "v_lshl_add_u64 shifted source = last pair", "v_lshl_add_u64 addend = last pair", "v_lshlrev_b64  destination = last pair"};
+    "v_lshl_add_u64 shifted source = last pair", "v_lshl_add_u64 addend = last pair", "v_lshlrev_b64  destination = last pair",
+    "v_lshlrev_b64  amount = last VGPR, data = constant -1", "v_lshrrev_b64  amount = last VGPR, data = constant -1",
+    "v_lshlrev_b64  amount = last-but-one, data = constant -1", "v_ashrrev_i64  amount = last VGPR, data = constant -2",
+    "v_lshlrev_b64  amount = last VGPR, data = SGPR pair"};
 
-template <int F>
+// LD 1: a load of the lane's own amount word into v12 is issued right before and left in flight across the shift (the
+// failing loops of seg_loop.hip have dependent loads in flight; its variants without loads do not fail)
+#define LOADP ".if %c[ld] == 1\n\tglobal_load_dword v12, %[lp], off\n\t.endif\n\t"
+#define LOADP14 ".if %c[ld] == 1\n\tglobal_load_dword v14, %[lp], off\n\t.endif\n\t"      // into the register next to the amount
+#define WAITP "\n\ts_waitcnt vmcnt(0)"
+template <int F, int GAP, int LD>
 __global__ __launch_bounds__(256) void shift_kernel(const uint64_t *in, const int *amt, uint64_t *out, size_t n, int uniform_amt)
 {
     const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -47,32 +61,43 @@ __global__ __launch_bounds__(256) void shift_kernel(const uint64_t *in, const in
     const uint64_t y = in[n - 1 - g];                  // second 64-bit operand of the add forms
     uint64_t r = 0;
     if (F == F_LSHL_AMT_LAST)
-        asm volatile("v_mov_b32 v15, %2\n\ts_nop 1\n\tv_lshlrev_b64 %0, v15, %1" : "=v"(r) : "v"(x), "v"(a) : "v15");
+        asm volatile(LOADP "v_mov_b32 v15, %2\n\t.if %c[gap] == 1\n\ts_nop 1\n\t.endif\n\tv_lshlrev_b64 %0, v15, %1" WAITP : "=v"(r) : "v"(x), "v"(a), [gap] "n"(GAP), [ld] "n"(LD), [lp] "v"(amt + g) : "v12", "v15", "memory");
     else if (F == F_LSHR_AMT_LAST)
-        asm volatile("v_mov_b32 v15, %2\n\ts_nop 1\n\tv_lshrrev_b64 %0, v15, %1" : "=v"(r) : "v"(x), "v"(a) : "v15");
+        asm volatile(LOADP "v_mov_b32 v15, %2\n\t.if %c[gap] == 1\n\ts_nop 1\n\t.endif\n\tv_lshrrev_b64 %0, v15, %1" WAITP : "=v"(r) : "v"(x), "v"(a), [gap] "n"(GAP), [ld] "n"(LD), [lp] "v"(amt + g) : "v12", "v15", "memory");
     else if (F == F_ASHR_AMT_LAST)
-        asm volatile("v_mov_b32 v15, %2\n\ts_nop 1\n\tv_ashrrev_i64 %0, v15, %1" : "=v"(r) : "v"(x), "v"(a) : "v15");
+        asm volatile(LOADP "v_mov_b32 v15, %2\n\t.if %c[gap] == 1\n\ts_nop 1\n\t.endif\n\tv_ashrrev_i64 %0, v15, %1" WAITP : "=v"(r) : "v"(x), "v"(a), [gap] "n"(GAP), [ld] "n"(LD), [lp] "v"(amt + g) : "v12", "v15", "memory");
     else if (F == F_LSHL_AMT_NOT_LAST)
-        asm volatile("v_mov_b32 v14, %2\n\ts_nop 1\n\tv_lshlrev_b64 %0, v14, %1" : "=v"(r) : "v"(x), "v"(a) : "v14", "v15");
+        asm volatile(LOADP "v_mov_b32 v14, %2\n\t.if %c[gap] == 1\n\ts_nop 1\n\t.endif\n\tv_lshlrev_b64 %0, v14, %1" WAITP : "=v"(r) : "v"(x), "v"(a), [gap] "n"(GAP), [ld] "n"(LD), [lp] "v"(amt + g) : "v12", "v14", "v15", "memory");
     else if (F == F_LSHL_DATA_LAST)
-        asm volatile("v_mov_b32 v14, %1\n\tv_mov_b32 v15, %2\n\ts_nop 1\n\tv_lshlrev_b64 %0, %3, v[14:15]"
-                     : "=v"(r) : "v"((uint32_t)x), "v"((uint32_t)(x >> 32)), "v"(a) : "v14", "v15");
+        asm volatile(LOADP "v_mov_b32 v14, %1\n\tv_mov_b32 v15, %2\n\t.if %c[gap] == 1\n\ts_nop 1\n\t.endif\n\tv_lshlrev_b64 %0, %3, v[14:15]" WAITP
+                     : "=v"(r) : "v"((uint32_t)x), "v"((uint32_t)(x >> 32)), "v"(a), [gap] "n"(GAP), [ld] "n"(LD), [lp] "v"(amt + g) : "v12", "v14", "v15", "memory");
     else if (F == F_LSHL_SGPR_AMT)
-        asm volatile("v_mov_b32 v14, %1\n\tv_mov_b32 v15, %2\n\ts_mov_b32 s20, %3\n\ts_nop 1\n\tv_lshlrev_b64 %0, s20, v[14:15]"
-                     : "=v"(r) : "v"((uint32_t)x), "v"((uint32_t)(x >> 32)), "s"(uniform_amt) : "v14", "v15", "s20");
+        asm volatile(LOADP "v_mov_b32 v14, %1\n\tv_mov_b32 v15, %2\n\ts_mov_b32 s20, %3\n\t.if %c[gap] == 1\n\ts_nop 1\n\t.endif\n\tv_lshlrev_b64 %0, s20, v[14:15]" WAITP
+                     : "=v"(r) : "v"((uint32_t)x), "v"((uint32_t)(x >> 32)), "s"(uniform_amt), [gap] "n"(GAP), [ld] "n"(LD), [lp] "v"(amt + g) : "v12", "v14", "v15", "s20", "memory");
     else if (F == F_LSHL_CONST_AMT)
-        asm volatile("v_mov_b32 v14, %1\n\tv_mov_b32 v15, %2\n\ts_nop 1\n\tv_lshlrev_b64 %0, 5, v[14:15]"
-                     : "=v"(r) : "v"((uint32_t)x), "v"((uint32_t)(x >> 32)) : "v14", "v15");
+        asm volatile(LOADP "v_mov_b32 v14, %1\n\tv_mov_b32 v15, %2\n\t.if %c[gap] == 1\n\ts_nop 1\n\t.endif\n\tv_lshlrev_b64 %0, 5, v[14:15]" WAITP
+                     : "=v"(r) : "v"((uint32_t)x), "v"((uint32_t)(x >> 32)), [gap] "n"(GAP), [ld] "n"(LD), [lp] "v"(amt + g) : "v12", "v14", "v15", "memory");
     else if (F == F_LSHL_ADD_SRC_LAST)
-        asm volatile("v_mov_b32 v14, %1\n\tv_mov_b32 v15, %2\n\ts_nop 1\n\tv_lshl_add_u64 %0, v[14:15], 3, %3"
-                     : "=v"(r) : "v"((uint32_t)x), "v"((uint32_t)(x >> 32)), "v"(y) : "v14", "v15");
+        asm volatile(LOADP "v_mov_b32 v14, %1\n\tv_mov_b32 v15, %2\n\t.if %c[gap] == 1\n\ts_nop 1\n\t.endif\n\tv_lshl_add_u64 %0, v[14:15], 3, %3" WAITP
+                     : "=v"(r) : "v"((uint32_t)x), "v"((uint32_t)(x >> 32)), "v"(y), [gap] "n"(GAP), [ld] "n"(LD), [lp] "v"(amt + g) : "v12", "v14", "v15", "memory");
     else if (F == F_LSHL_ADD_ADD_LAST)
-        asm volatile("v_mov_b32 v14, %1\n\tv_mov_b32 v15, %2\n\ts_nop 1\n\tv_lshl_add_u64 %0, %3, 3, v[14:15]"
-                     : "=v"(r) : "v"((uint32_t)y), "v"((uint32_t)(y >> 32)), "v"(x) : "v14", "v15");
+        asm volatile(LOADP "v_mov_b32 v14, %1\n\tv_mov_b32 v15, %2\n\t.if %c[gap] == 1\n\ts_nop 1\n\t.endif\n\tv_lshl_add_u64 %0, %3, 3, v[14:15]" WAITP
+                     : "=v"(r) : "v"((uint32_t)y), "v"((uint32_t)(y >> 32)), "v"(x), [gap] "n"(GAP), [ld] "n"(LD), [lp] "v"(amt + g) : "v12", "v14", "v15", "memory");
+    else if (F == F_LSHL_CONST_DATA)
+        asm volatile(LOADP14 "v_mov_b32 v15, %1\n\t.if %c[gap] == 1\n\ts_nop 1\n\t.endif\n\tv_lshlrev_b64 %0, v15, -1" WAITP : "=v"(r) : "v"(a), [gap] "n"(GAP), [ld] "n"(LD), [lp] "v"(amt + g) : "v14", "v15", "memory");
+    else if (F == F_LSHR_CONST_DATA)
+        asm volatile(LOADP14 "v_mov_b32 v15, %1\n\t.if %c[gap] == 1\n\ts_nop 1\n\t.endif\n\tv_lshrrev_b64 %0, v15, -1" WAITP : "=v"(r) : "v"(a), [gap] "n"(GAP), [ld] "n"(LD), [lp] "v"(amt + g) : "v14", "v15", "memory");
+    else if (F == F_LSHL_CONST_DATA_NL)
+        asm volatile(LOADP "v_mov_b32 v14, %1\n\t.if %c[gap] == 1\n\ts_nop 1\n\t.endif\n\tv_lshlrev_b64 %0, v14, -1" WAITP : "=v"(r) : "v"(a), [gap] "n"(GAP), [ld] "n"(LD), [lp] "v"(amt + g) : "v12", "v14", "v15", "memory");
+    else if (F == F_ASHR_CONST_DATA)
+        asm volatile(LOADP14 "v_mov_b32 v15, %1\n\t.if %c[gap] == 1\n\ts_nop 1\n\t.endif\n\tv_ashrrev_i64 %0, v15, -2" WAITP : "=v"(r) : "v"(a), [gap] "n"(GAP), [ld] "n"(LD), [lp] "v"(amt + g) : "v14", "v15", "memory");
+    else if (F == F_LSHL_SGPR_DATA)
+        asm volatile(LOADP14 "v_mov_b32 v15, %1\n\ts_mov_b32 s20, 0x89abcdef\n\ts_mov_b32 s21, 0x01234567\n\t.if %c[gap] == 1\n\ts_nop 1\n\t.endif\n\tv_lshlrev_b64 %0, v15, s[20:21]" WAITP
+                     : "=v"(r) : "v"(a), [gap] "n"(GAP), [ld] "n"(LD), [lp] "v"(amt + g) : "v14", "v15", "s20", "s21", "memory");
     else if (F == F_LSHL_DST_LAST) {
         uint32_t lo, hi;
-        asm volatile("v_lshlrev_b64 v[14:15], %2, %3\n\ts_nop 1\n\tv_mov_b32 %0, v14\n\tv_mov_b32 %1, v15"
-                     : "=v"(lo), "=v"(hi) : "v"(a), "v"(x) : "v14", "v15");
+        asm volatile(LOADP "v_lshlrev_b64 v[14:15], %2, %3\n\t.if %c[gap] == 1\n\ts_nop 1\n\t.endif\n\tv_mov_b32 %0, v14\n\tv_mov_b32 %1, v15" WAITP
+                     : "=v"(lo), "=v"(hi) : "v"(a), "v"(x), [gap] "n"(GAP), [ld] "n"(LD), [lp] "v"(amt + g) : "v12", "v14", "v15", "memory");
         r = ((uint64_t)hi << 32) | lo;
     }
     out[g] = r;
@@ -87,15 +112,21 @@ static uint64_t expect(int f, uint64_t x, uint64_t y, int a, int ua)
     case F_LSHL_SGPR_AMT: return x << (ua & 63);
     case F_LSHL_CONST_AMT: return x << 5;
     case F_LSHL_ADD_SRC_LAST: return (x << 3) + y;
-    case F_LSHL_ADD_ADD_LAST: return (x << 3) + y;      // (operands swapped in the kernel: src = x, addend = y's registers hold... see below)
+    case F_LSHL_ADD_ADD_LAST: return (x << 3) + y;
+    case F_LSHL_CONST_DATA: case F_LSHL_CONST_DATA_NL: return ~0ull << (a & 63);
+    case F_LSHR_CONST_DATA: return ~0ull >> (a & 63);
+    case F_ASHR_CONST_DATA: return (uint64_t)((int64_t)-2 >> (a & 63));
+    case F_LSHL_SGPR_DATA: return 0x0123456789abcdefull << (a & 63);
     }
     return 0;
 }
 
 template <int F>
-static void launch(dim3 grid, const uint64_t *in, const int *amt, uint64_t *out, size_t n, int ua)
+static void launch(int gap, dim3 grid, const uint64_t *in, const int *amt, uint64_t *out, size_t n, int ua)
 {
-    hipLaunchKernelGGL((shift_kernel<F>), grid, dim3(256), 0, 0, in, amt, out, n, ua);
+    if (gap == 1) hipLaunchKernelGGL((shift_kernel<F, 1, 0>), grid, dim3(256), 0, 0, in, amt, out, n, ua);
+    else if (gap == 0) hipLaunchKernelGGL((shift_kernel<F, 0, 0>), grid, dim3(256), 0, 0, in, amt, out, n, ua);
+    else hipLaunchKernelGGL((shift_kernel<F, 0, 1>), grid, dim3(256), 0, 0, in, amt, out, n, ua);
 }
 
 int main(int argc, char **argv)
@@ -116,21 +147,27 @@ int main(int argc, char **argv)
     const dim3 grid((unsigned)((n + 255) / 256));
     const int ua = 13;
     printf("64-bit shift forms with an operand in the last registers of a 16-VGPR allocation: wrong results of %zu lanes x %d launches\n", n, reps);
+    for (int gap = 0; gap < 3; ++gap)
     for (int f = 0; f < F_COUNT; ++f) {
         long wrong = 0; int shown = 0;
         for (int r = 0; r < reps; ++r) {
             CK(hipMemset(d_out, 0xee, n * 8));
             switch (f) {
-            case 0: launch<0>(grid, d_in, d_amt, d_out, n, ua); break;
-            case 1: launch<1>(grid, d_in, d_amt, d_out, n, ua); break;
-            case 2: launch<2>(grid, d_in, d_amt, d_out, n, ua); break;
-            case 3: launch<3>(grid, d_in, d_amt, d_out, n, ua); break;
-            case 4: launch<4>(grid, d_in, d_amt, d_out, n, ua); break;
-            case 5: launch<5>(grid, d_in, d_amt, d_out, n, ua); break;
-            case 6: launch<6>(grid, d_in, d_amt, d_out, n, ua); break;
-            case 7: launch<7>(grid, d_in, d_amt, d_out, n, ua); break;
-            case 8: launch<8>(grid, d_in, d_amt, d_out, n, ua); break;
-            case 9: launch<9>(grid, d_in, d_amt, d_out, n, ua); break;
+            case 0: launch<0>(gap, grid, d_in, d_amt, d_out, n, ua); break;
+            case 1: launch<1>(gap, grid, d_in, d_amt, d_out, n, ua); break;
+            case 2: launch<2>(gap, grid, d_in, d_amt, d_out, n, ua); break;
+            case 3: launch<3>(gap, grid, d_in, d_amt, d_out, n, ua); break;
+            case 4: launch<4>(gap, grid, d_in, d_amt, d_out, n, ua); break;
+            case 5: launch<5>(gap, grid, d_in, d_amt, d_out, n, ua); break;
+            case 6: launch<6>(gap, grid, d_in, d_amt, d_out, n, ua); break;
+            case 7: launch<7>(gap, grid, d_in, d_amt, d_out, n, ua); break;
+            case 8: launch<8>(gap, grid, d_in, d_amt, d_out, n, ua); break;
+            case 9: launch<9>(gap, grid, d_in, d_amt, d_out, n, ua); break;
+            case 10: launch<10>(gap, grid, d_in, d_amt, d_out, n, ua); break;
+            case 11: launch<11>(gap, grid, d_in, d_amt, d_out, n, ua); break;
+            case 12: launch<12>(gap, grid, d_in, d_amt, d_out, n, ua); break;
+            case 13: launch<13>(gap, grid, d_in, d_amt, d_out, n, ua); break;
+            case 14: launch<14>(gap, grid, d_in, d_amt, d_out, n, ua); break;
             }
             CK(hipGetLastError());
             CK(hipDeviceSynchronize());
@@ -145,7 +182,7 @@ int main(int argc, char **argv)
                 }
             }
         }
-        printf("  %-52s %s (%ld wrong)\n", form_name[f], wrong ? "FAILS" : "ok", wrong);
+        printf("  %-52s %-34s %s (%ld wrong)\n", form_name[f], gap == 1 ? "two wait states before the shift" : (gap == 0 ? "operand written just before" : "a load in flight across the shift"), wrong ? "FAILS" : "ok", wrong);
     }
     return 0;
 }

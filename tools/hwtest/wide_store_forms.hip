@@ -2,7 +2,7 @@
 // (round 2)")  tools/hwtest/wide_store.hip showed it for buffer_store_dwordx4 with a REGISTER scalar
 // offset, the one form for which the compiler inserts no wait state.  This program runs the same experiment -- store good
 // data, overwrite the first data registers in the very next instruction, count what reached memory -- for the other
-// forms, each with NO wait state and with one (`s_nop 0`):
+// forms, each with NO wait state, with one (`s_nop 0`) and with two (`s_nop 1`, what the compiler inserts where it knows the hazard):
 //
 //   hipcc --offload-arch=gfx950 -O2 -o tools/hwtest/wide_store_forms tools/hwtest/wide_store_forms.hip && tools/hwtest/wide_store_forms
 //
@@ -27,7 +27,7 @@ static const char *const form_name[FORMS] = {"buffer_store_dwordx2, register sof
 static const int form_dwords[FORMS] = {2, 3, 4, 3, 4, 2, 3, 4};
 
 #define FILL "v_mov_b32 v20, %0\n\tv_mov_b32 v21, %0\n\tv_mov_b32 v22, %0\n\tv_mov_b32 v23, %0\n\ts_nop 4\n\t"
-#define GAP ".if %5 == 1\n\ts_nop 0\n\t.endif\n\t"
+#define GAP ".if %5 == 1\n\ts_nop 0\n\t.endif\n\t.if %5 == 2\n\ts_nop 1\n\t.endif\n\t"
 #define SPOIL "v_mov_b32 v20, %4\n\tv_mov_b32 v21, %4\n\ts_waitcnt vmcnt(0)"
 
 template <int F, int NOPS>
@@ -90,9 +90,9 @@ static long run(uint32_t *d_out, size_t dwords, int blocks, std::vector<uint32_t
 template <int F>
 static void form(uint32_t *d_out, size_t dwords, int blocks, std::vector<uint32_t> &h)
 {
-    const long n0 = run<F, 0>(d_out, dwords, blocks, h), n1 = run<F, 1>(d_out, dwords, blocks, h);
-    printf("  %-42s no wait state: %9ld wrong   s_nop 0: %9ld wrong   -> %s\n", form_name[F], n0, n1,
-           n0 ? (n1 ? "needs MORE than one wait state" : "needs a wait state") : "no hazard seen");
+    const long n0 = run<F, 0>(d_out, dwords, blocks, h), n1 = run<F, 1>(d_out, dwords, blocks, h), n2 = run<F, 2>(d_out, dwords, blocks, h);
+    printf("  %-42s no wait state: %9ld wrong   s_nop 0: %9ld   s_nop 1: %9ld   -> %s\n", form_name[F], n0, n1, n2,
+           n0 ? (n1 ? (n2 ? "needs MORE than two wait states" : "needs two wait states") : "needs a wait state") : "no hazard seen");
 }
 
 int main()
