@@ -275,12 +275,61 @@ __device__ __forceinline__ uint32_t nibbles4(uint32_t d)
     return (d | (d >> 8)) & 0xffffu;
 }
 
+// ---- the row pre-test (FAST tiles) ----------------------------------------------------------------------------------
+// Most pixels of most footage can be neither "damaged" nor "bright background", and that can be PROVED from the smallest
+// and the largest of a pixel's temporal neighbours, without the outlier cut:
+//   * the background is a mean of a non-empty subset of the neighbours (or of all of them), rounded to f32: it lies in
+//     [min b, max b], whichever subset the reference's cut keeps and whatever pixel_std_coeff is;
+//   * `background > brightness_threshold` (ip.py:743) therefore needs  max b > brightness_threshold;
+//   * the damage threshold 30 + (bg / 255) * 225 (ip.py:638; the constants are the reference's own) does not decrease with
+//     bg, so `pixel > threshold` needs  pixel > 30 + (min b / 255) * 225, and the three f32 roundings move the right side by
+//     less than 1e-4: in integers, 255 pixel >= 7649 + 225 min b is NECESSARY (one unit of 1/255 of slack).
+// Both are evaluated for four pixels at once on 16-bit lanes (every quantity is below 2^16): even / odd bytes of each
+// neighbour dword, packed min / max, one packed multiply-add and one saturating subtraction per test.  Only if some lane
+// of the wave has a pixel that passes one of the two does the wave run the outlier cut for that row (bit-exact as before:
+// the pre-test only ever skips pixels whose two result bits are provably zero).  On the benchmark's footage 2 % of the
+// wave-rows run the cut; an all-bright scene runs it everywhere and pays the pre-test on top (+12 %).
+typedef unsigned short ipx_u16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ ipx_u16x2 even_bytes(uint32_t v) { return __builtin_bit_cast(ipx_u16x2, v & 0x00ff00ffu); }
+__device__ __forceinline__ ipx_u16x2 odd_bytes(uint32_t v) { return __builtin_bit_cast(ipx_u16x2, __builtin_amdgcn_perm(v, v, 0x0c030c01u)); }
+
+struct PreTest {
+    ipx_u16x2 k255, k225, k7648, kbright;      // constants of the two tests, in both halves
+    bool on;                                   // brightness_threshold in [0, 65535): else every row runs the cut
+};
+__device__ __forceinline__ PreTest pretest_prepare(float bg_gt)
+{
+    PreTest t;
+    t.on = bg_gt >= 0.f && bg_gt < 65535.f;
+    const unsigned short kb = t.on ? (unsigned short)floorf(bg_gt) : (unsigned short)0;   // max b > bg_gt  <=>  max b > floor(bg_gt)
+    t.k255 = ipx_u16x2{255, 255}; t.k225 = ipx_u16x2{225, 225}; t.k7648 = ipx_u16x2{7648, 7648}; t.kbright = ipx_u16x2{kb, kb};
+    return t;
+}
+// nonzero iff one of the four pixels of `cen` may get a result bit, given its neighbours' packed min / max
+__device__ __forceinline__ uint32_t pretest_four(const PreTest &t, uint32_t cen, ipx_u16x2 mnE, ipx_u16x2 mnO, ipx_u16x2 mxE, ipx_u16x2 mxO)
+{
+    const ipx_u16x2 dE = __builtin_elementwise_sub_sat(even_bytes(cen) * t.k255, mnE * t.k225 + t.k7648);   // > 0: 255 p >= 7649 + 225 min
+    const ipx_u16x2 dO = __builtin_elementwise_sub_sat(odd_bytes(cen) * t.k255, mnO * t.k225 + t.k7648);
+    const ipx_u16x2 bE = __builtin_elementwise_sub_sat(mxE, t.kbright), bO = __builtin_elementwise_sub_sat(mxO, t.kbright);
+    return (__builtin_bit_cast(uint32_t, dE) | __builtin_bit_cast(uint32_t, dO)) | (__builtin_bit_cast(uint32_t, bE) | __builtin_bit_cast(uint32_t, bO));
+}
+
 // Phase C of detect_kernel for one thread (see there).  FULL: the frame has all MAXN temporal neighbours.
 // FAST: the neighbour rows are read as aligned dwords at a 32-bit offset from a per-frame base that is uniform
 // over the workgroup (scalar registers), one add per row; no per-pixel bounds tests.
+//
+// FAST tiles first SCAN: the row pre-test (pretest_four) on every group of four pixels, no outlier cut.  A group that
+// passes the pre-test (on the benchmark's footage 1.4 % of them: a hot pixel, or one of the six frames around a hot
+// pixel, or the bright block) is appended to a work list in LDS, and when the scan is done the workgroup's threads take
+// the list's entries one each -- dense lanes for the expensive code instead of a wave that runs it for 64 lanes because
+// one of them needs it.  A tile whose list overflows (bright background) runs the cut for all of its groups in the
+// per-row loop instead, as tiles without the pre-test do: the dense case, which then costs the scan on top (+15 %).
+constexpr int WORK_CAP = 512;                // groups of four pixels per tile that can wait in the list (of 2048)
+
 template <int MAXN, bool FULL, bool FAST>
 __device__ __forceinline__ void pixel_rows(const DetectArgs &a, const uint8_t *s_win, const uint16_t *s_hs,
                                            uint8_t (*s_nib)[TH][TW / 4], const double *s_rcp, const float *s_rcpf,
+                                           unsigned int *s_nwork, unsigned short *s_work,
                                            int x0, int y0, int fi, int lo, int nn, int cpos,
                                            unsigned int &c_lt, unsigned int &c_gt)
 {
@@ -295,10 +344,11 @@ __device__ __forceinline__ void pixel_rows(const DetectArgs &a, const uint8_t *s
     const int cg = tid & 31, rg = tid >> 5;
     const int gx = x0 + 4 * cg;
     const bool col_live = gx < W;
-    int vs[4] = {0, 0, 0, 0};
-    {
+    // the 30-row sums of the window whose top row is `top`, for the four columns of group `grp`
+    auto vsum_at = [&](int top, int grp, int (&vs)[4]) {
+        vs[0] = vs[1] = vs[2] = vs[3] = 0;
         // 30 rows of packed u16 pairs: up to 8 rows (8 * 30 * 255 < 2^16) are added as whole dwords before widening
-        const uint16_t *hp = s_hs + (RG * rg) * HS_STRIDE + 4 * cg;
+        const uint16_t *hp = s_hs + top * HS_STRIDE + 4 * grp;
 #pragma unroll
         for (int g = 0; g < KS; g += 8) {
             uint32_t px = 0, py = 0;
@@ -309,13 +359,16 @@ __device__ __forceinline__ void pixel_rows(const DetectArgs &a, const uint8_t *s
             }
             vs[0] += px & 0xffff; vs[1] += px >> 16; vs[2] += py & 0xffff; vs[3] += py >> 16;
         }
-    }
+    };
+    int vs[4];
     const SwarGt sw_gt = swar_gt_prepare(a.frame_gt), sw_ge = swar_gt_prepare(a.est_lt - 1);
+    const PreTest pt = pretest_prepare(a.bg_gt);
+    const bool listed = FAST && pt.on;                       // workgroup-uniform: the pre-test and the work list are in use
     const size_t P = (size_t)H * W;
-    // neighbour frames of one row: slot s holds frame lo + s (+1 from the centre on)
-    auto load_row = [&](int gy, uint32_t (&v)[MAXN]) {
+    // neighbour frames of one row of group column `x`: slot s holds frame lo + s (+1 from the centre on)
+    auto load_row = [&](int gy, int x, uint32_t (&v)[MAXN]) {
         if (FAST) {
-            const unsigned off = (unsigned)(min(gy, H - 1) * W + gx);
+            const unsigned off = (unsigned)(min(gy, H - 1) * W + x);
 #pragma unroll
             for (int s = 0; s < MAXN; ++s) {
                 const uint8_t *fb = a.frames + (size_t)(lo + s + (s >= cpos ? 1 : 0)) * P;    // uniform
@@ -325,72 +378,142 @@ __device__ __forceinline__ void pixel_rows(const DetectArgs &a, const uint8_t *s
 #pragma unroll
             for (int s = 0; s < MAXN; ++s) {
                 const int f = lo + s + (s >= cpos ? 1 : 0);
-                v[s] = (s < nn && col_live && gy < H) ? load4(a.frames + ((size_t)f * H + gy) * W, gx, W, aligned) : 0u;
+                v[s] = (s < nn && col_live && gy < H) ? load4(a.frames + ((size_t)f * H + gy) * W, x, W, aligned) : 0u;
             }
         }
     };
-    uint32_t vnext[MAXN];
-    load_row(y0 + RG * rg, vnext);
+    // the outlier cut and the two tests for the four pixels of `cen` (neighbour dwords v, window sums ws) -> two nibbles
+    auto cut_four = [&](const uint32_t (&v)[MAXN], uint32_t cen, const int (&ws)[4], int gy, int x, uint32_t &dm, uint32_t &bm,
+                        unsigned &lt, unsigned &gt) {
+        BgSums sm[4];
+        bool any_hard = !bc.unit_coeff;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            sm[j] = background_sums<MAXN, FULL>(v, j, bc);
+            any_hard |= sm[j].hard;
+        }
+        float bgv[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bgv[j] = div_small((float)sm[j].Si, (float)sm[j].c, s_rcpf[sm[j].c]);   // c >= 1
+        if (__builtin_expect(any_hard, 0)) {
+            NeighbourRow<MAXN> row;
+#pragma unroll
+            for (int s = 0; s < MAXN; ++s) row.v[s] = v[s];
+            for (int j = 0; j < 4; ++j)
+                if (sm[j].hard || !bc.unit_coeff) {
+                    const float h = background_hard<MAXN>(row, j, FULL ? MAXN : nn, a.coeff, s_rcp);
+                    bgv[0] = j == 0 ? h : bgv[0]; bgv[1] = j == 1 ? h : bgv[1];
+                    bgv[2] = j == 2 ? h : bgv[2]; bgv[3] = j == 3 ? h : bgv[3];
+                }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (FAST || x + j < W) {
+                const int pix = (int)__builtin_amdgcn_ubfe(cen, 8 * j, 8);
+                const float bg = bgv[j];
+                if (!FAST && a.bg_out) a.bg_out[(size_t)gy * W + x + j] = bg;
+                const float thr = damage_threshold_f32(bg);
+                const bool dmg = ((float)pix > thr) && (900 * pix > ws[j]);
+                dm |= (uint32_t)dmg << j;
+                bm |= (uint32_t)(bg > a.bg_gt) << j;
+                if (!FAST) { lt += pix < a.est_lt; gt += pix > a.frame_gt; }
+            }
+        }
+    };
+    // the per-row loop that runs the cut for every group (tiles without the pre-test, and tiles whose list overflowed)
+    auto dense_rows = [&]() {
+        uint32_t vnext[MAXN];
+        load_row(y0 + RG * rg, gx, vnext);
 #pragma unroll 1
-    for (int r = 0; r < RG; ++r) {
-        const int ty = RG * rg + r;
-        const int gy = y0 + ty;
-        uint32_t v[MAXN];
+        for (int r = 0; r < RG; ++r) {
+            const int ty = RG * rg + r;
+            const int gy = y0 + ty;
+            uint32_t v[MAXN];
 #pragma unroll
-        for (int s = 0; s < MAXN; ++s) v[s] = vnext[s];
-        if (r + 1 < RG) load_row(gy + 1, vnext);             // in flight under this row's arithmetic
-        uint32_t dm = 0, bm = 0;
-        if (FAST || (gy < H && col_live)) {
-            const uint32_t cen = *reinterpret_cast<const uint32_t *>(s_win + (ty + AX) * WIN_STRIDE + 16 + 4 * cg);
-            unsigned lt = 0, gt = 0;
-            BgSums sm[4];
-            bool any_hard = !bc.unit_coeff;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                sm[j] = background_sums<MAXN, FULL>(v, j, bc);
-                any_hard |= sm[j].hard;
-            }
-            float bgv[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) bgv[j] = div_small((float)sm[j].Si, (float)sm[j].c, s_rcpf[sm[j].c]);   // c >= 1
-            if (__builtin_expect(any_hard, 0)) {
-                NeighbourRow<MAXN> row;
-#pragma unroll
-                for (int s = 0; s < MAXN; ++s) row.v[s] = v[s];
-                for (int j = 0; j < 4; ++j)
-                    if (sm[j].hard || !bc.unit_coeff) {
-                        const float h = background_hard<MAXN>(row, j, FULL ? MAXN : nn, a.coeff, s_rcp);
-                        bgv[0] = j == 0 ? h : bgv[0]; bgv[1] = j == 1 ? h : bgv[1];
-                        bgv[2] = j == 2 ? h : bgv[2]; bgv[3] = j == 3 ? h : bgv[3];
-                    }
-            }
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                if (FAST || gx + j < W) {
-                    const int pix = (int)__builtin_amdgcn_ubfe(cen, 8 * j, 8);
-                    const float bg = bgv[j];
-                    if (!FAST && a.bg_out) a.bg_out[(size_t)gy * W + gx + j] = bg;
-                    const float thr = damage_threshold_f32(bg);
-                    const bool dmg = ((float)pix > thr) && (900 * pix > vs[j]);
-                    dm |= (uint32_t)dmg << j;
-                    bm |= (uint32_t)(bg > a.bg_gt) << j;
-                    if (!FAST) { lt += pix < a.est_lt; gt += pix > a.frame_gt; }
+            for (int s = 0; s < MAXN; ++s) v[s] = vnext[s];
+            if (r + 1 < RG) load_row(gy + 1, gx, vnext);     // in flight under this row's arithmetic
+            uint32_t dm = 0, bm = 0;
+            if (FAST || (gy < H && col_live)) {
+                const uint32_t cen = *reinterpret_cast<const uint32_t *>(s_win + (ty + AX) * WIN_STRIDE + 16 + 4 * cg);
+                unsigned lt = 0, gt = 0;
+                cut_four(v, cen, vs, gy, gx, dm, bm, lt, gt);
+                if (!listed) {                               // (a listed tile has counted its pixels in the scan)
+                    if (FAST) { gt = swar_count_gt(cen, sw_gt); lt = 4 - swar_count_gt(cen, sw_ge); }
+                    if (!FAST || gy < H) { c_lt += lt; c_gt += gt; }
                 }
             }
-            if (FAST) { gt = swar_count_gt(cen, sw_gt); lt = 4 - swar_count_gt(cen, sw_ge); }
-            if (!FAST || gy < H) { c_lt += lt; c_gt += gt; }
+            s_nib[0][ty][cg] = (uint8_t)dm;
+            s_nib[1][ty][cg] = (uint8_t)bm;
+            if (r + 1 < RG) {                                // slide the window one row down
+                const uint2 hin = *reinterpret_cast<const uint2 *>(s_hs + (ty + KS) * HS_STRIDE + 4 * cg);
+                const uint2 hout = *reinterpret_cast<const uint2 *>(s_hs + ty * HS_STRIDE + 4 * cg);
+                const ipx_u16x2 dx = __builtin_bit_cast(ipx_u16x2, hin.x) - __builtin_bit_cast(ipx_u16x2, hout.x);   // per lane, mod 2^16
+                const ipx_u16x2 dy = __builtin_bit_cast(ipx_u16x2, hin.y) - __builtin_bit_cast(ipx_u16x2, hout.y);
+                vs[0] += (int)(short)dx.x; vs[1] += (int)(short)dx.y;
+                vs[2] += (int)(short)dy.x; vs[3] += (int)(short)dy.y;
+            }
         }
-        s_nib[0][ty][cg] = (uint8_t)dm;
-        s_nib[1][ty][cg] = (uint8_t)bm;
-        if (r + 1 < RG) {                                    // slide the window one row down
-            const uint2 hin = *reinterpret_cast<const uint2 *>(s_hs + (ty + KS) * HS_STRIDE + 4 * cg);
-            const uint2 hout = *reinterpret_cast<const uint2 *>(s_hs + ty * HS_STRIDE + 4 * cg);
-            typedef unsigned short ipx_u16x2 __attribute__((ext_vector_type(2)));
-            const ipx_u16x2 dx = __builtin_bit_cast(ipx_u16x2, hin.x) - __builtin_bit_cast(ipx_u16x2, hout.x);   // per lane, mod 2^16
-            const ipx_u16x2 dy = __builtin_bit_cast(ipx_u16x2, hin.y) - __builtin_bit_cast(ipx_u16x2, hout.y);
-            vs[0] += (int)(short)dx.x; vs[1] += (int)(short)dx.y;
-            vs[2] += (int)(short)dy.x; vs[3] += (int)(short)dy.y;
+    };
+    if (!listed) {
+        vsum_at(RG * rg, cg, vs);
+        dense_rows();
+        return;
+    }
+    // ---- the scan: pre-test of the thread's 8 groups, the frame's pixel counters, zero nibbles.  Nothing in it is long
+    // enough to hide a load, so the rows' loads run four rows ahead (the loop is unrolled: the ring of rows is indexed
+    // statically).
+    {
+        constexpr int AHEAD = MAXN > 6 ? 2 : 4;             // (the 16-neighbour variant has no registers for more)
+        uint32_t ring[AHEAD][MAXN];
+#pragma unroll
+        for (int r = 0; r < AHEAD; ++r) load_row(y0 + RG * rg + r, gx, ring[r]);
+#pragma unroll
+        for (int r = 0; r < RG; ++r) {
+            const int ty = RG * rg + r;
+            const int gy = y0 + ty;
+            uint32_t v[MAXN];
+#pragma unroll
+            for (int s = 0; s < MAXN; ++s) v[s] = ring[r % AHEAD][s];
+            if (r + AHEAD < RG) load_row(gy + AHEAD, gx, ring[r % AHEAD]);
+            const uint32_t cen = *reinterpret_cast<const uint32_t *>(s_win + (ty + AX) * WIN_STRIDE + 16 + 4 * cg);
+            ipx_u16x2 mnE = even_bytes(v[0]), mnO = odd_bytes(v[0]), mxE = mnE, mxO = mnO;
+#pragma unroll
+            for (int s = 1; s < MAXN; ++s)
+                if (FULL || s < nn) {                        // workgroup-uniform
+                    const ipx_u16x2 e = even_bytes(v[s]), o = odd_bytes(v[s]);
+                    mnE = __builtin_elementwise_min(mnE, e); mnO = __builtin_elementwise_min(mnO, o);
+                    mxE = __builtin_elementwise_max(mxE, e); mxO = __builtin_elementwise_max(mxO, o);
+                }
+            if (pretest_four(pt, cen, mnE, mnO, mxE, mxO) != 0u) {               // rare, divergent
+                const unsigned slot = atomicAdd(s_nwork, 1u);
+                if (slot < (unsigned)WORK_CAP) s_work[slot] = (unsigned short)((ty << 5) | cg);
+            }
+            if (gy < H) { c_gt += swar_count_gt(cen, sw_gt); c_lt += 4 - swar_count_gt(cen, sw_ge); }
+            s_nib[0][ty][cg] = 0;
+            s_nib[1][ty][cg] = 0;
         }
+    }
+    __syncthreads();                                         // the list is complete, every nibble has its zero
+    const unsigned nlisted = *s_nwork;
+    if (nlisted > (unsigned)WORK_CAP) {                      // workgroup-uniform: a dense tile (bright background): every group, in place
+        vsum_at(RG * rg, cg, vs);
+        dense_rows();
+        return;
+    }
+    // ---- the listed groups, one per thread: neighbour rows again (cache hits), window sums from the horizontal sums
+    for (int i = tid; i < (int)nlisted; i += 256) {
+        const int item = s_work[i], ty = item >> 5, grp = item & 31;
+        const int gy = y0 + ty, x = x0 + 4 * grp;
+        uint32_t v[MAXN];
+        load_row(gy, x, v);
+        int ws[4];
+        vsum_at(ty, grp, ws);
+        const uint32_t cen = *reinterpret_cast<const uint32_t *>(s_win + (ty + AX) * WIN_STRIDE + 16 + 4 * grp);
+        uint32_t dm = 0, bm = 0;
+        unsigned lt = 0, gt = 0;
+        cut_four(v, cen, ws, gy, x, dm, bm, lt, gt);
+        s_nib[0][ty][grp] = (uint8_t)dm;
+        s_nib[1][ty][grp] = (uint8_t)bm;
     }
 }
 
@@ -401,6 +524,8 @@ __global__ __launch_bounds__(256) void detect_kernel(DetectArgs a)
     __shared__ __attribute__((aligned(16))) uint16_t s_hs[WIN_H * HS_STRIDE];
     __shared__ __attribute__((aligned(16))) uint8_t s_nib[2][TH][TW / 4];      // damaged / bright nibbles per 4 pixels
     __shared__ unsigned int s_cnt[2];
+    __shared__ unsigned int s_nwork;                                           // groups in the work list (may count past WORK_CAP)
+    __shared__ unsigned short s_work[WORK_CAP];                                // (tile row << 5) | group of four columns
     __shared__ double s_rcp[MAXN + 1];
     __shared__ float s_rcpf[MAXN + 1];
 
@@ -430,6 +555,7 @@ __global__ __launch_bounds__(256) void detect_kernel(DetectArgs a)
         return;
     }
     if (tid < 2) s_cnt[tid] = 0;
+    if (tid == 2) s_nwork = 0;
     if (tid <= MAXN) { s_rcp[tid] = tid ? 1.0 / (double)tid : 0.0; s_rcpf[tid] = tid ? 1.0f / (float)tid : 0.0f; }
 
     const uint8_t *frame = a.frames + (size_t)fi * H * W;
@@ -510,10 +636,10 @@ __global__ __launch_bounds__(256) void detect_kernel(DetectArgs a)
     // computed from the last row and dropped), nothing but the two planes leaves the kernel
     const bool fast = aligned && x0 + TW <= W && a.bg_out == nullptr;
     unsigned int c_lt = 0, c_gt = 0;
-    if (full && fast) pixel_rows<MAXN, true, true>(a, s_win, s_hs, s_nib, s_rcp, s_rcpf, x0, y0, fi, lo, nn, cpos, c_lt, c_gt);
-    else if (full) pixel_rows<MAXN, true, false>(a, s_win, s_hs, s_nib, s_rcp, s_rcpf, x0, y0, fi, lo, nn, cpos, c_lt, c_gt);
-    else if (fast) pixel_rows<MAXN, false, true>(a, s_win, s_hs, s_nib, s_rcp, s_rcpf, x0, y0, fi, lo, nn, cpos, c_lt, c_gt);
-    else pixel_rows<MAXN, false, false>(a, s_win, s_hs, s_nib, s_rcp, s_rcpf, x0, y0, fi, lo, nn, cpos, c_lt, c_gt);
+    if (full && fast) pixel_rows<MAXN, true, true>(a, s_win, s_hs, s_nib, s_rcp, s_rcpf, &s_nwork, s_work, x0, y0, fi, lo, nn, cpos, c_lt, c_gt);
+    else if (full) pixel_rows<MAXN, true, false>(a, s_win, s_hs, s_nib, s_rcp, s_rcpf, &s_nwork, s_work, x0, y0, fi, lo, nn, cpos, c_lt, c_gt);
+    else if (fast) pixel_rows<MAXN, false, true>(a, s_win, s_hs, s_nib, s_rcp, s_rcpf, &s_nwork, s_work, x0, y0, fi, lo, nn, cpos, c_lt, c_gt);
+    else pixel_rows<MAXN, false, false>(a, s_win, s_hs, s_nib, s_rcp, s_rcpf, &s_nwork, s_work, x0, y0, fi, lo, nn, cpos, c_lt, c_gt);
     if (a.dense) {
         // wave-level reduce, then one LDS atomic per wave
         for (int off = 32; off > 0; off >>= 1) {

@@ -20,6 +20,8 @@ def main():
     dev = torch.device("cuda", 0)
     eng = Engine(0)
     fr = synth.chunk_torch(2, n, H, W, dev)
+    if os.environ.get("IPX_BRIGHT") == "1":   # an all-bright scene: every pixel's background is above brightness_threshold
+        fr = (fr.to(torch.int16) + 130).clamp_(0, 255).to(torch.uint8)   # (detect's row pre-test then never skips the outlier cut)
     keep = torch.ones(n, dtype=torch.uint8, device=dev)
     if stage == "flow":                       # the motion test alone: wall time per call (events on the launch stream)
         eng.flow_metric(fr)
