@@ -325,6 +325,8 @@ __device__ __forceinline__ uint32_t pretest_four(const PreTest &t, uint32_t cen,
 // one of them needs it.  A tile whose list overflows (bright background) runs the cut for all of its groups in the
 // per-row loop instead, as tiles without the pre-test do: the dense case, which then costs the scan on top (+15 %).
 constexpr int WORK_CAP = 512;                // groups of four pixels per tile that can wait in the list (of 2048)
+// rows of neighbour dwords the scan keeps in flight (the 16-neighbour variant has registers for one)
+template <int MAXN> struct SCAN_AHEAD { static constexpr int value = MAXN > 6 ? 1 : 4; };
 
 template <int MAXN, bool FULL, bool FAST>
 __device__ __forceinline__ void pixel_rows(const DetectArgs &a, const uint8_t *s_win, const uint16_t *s_hs,
@@ -461,9 +463,10 @@ __device__ __forceinline__ void pixel_rows(const DetectArgs &a, const uint8_t *s
     }
     // ---- the scan: pre-test of the thread's 8 groups, the frame's pixel counters, zero nibbles.  Nothing in it is long
     // enough to hide a load, so the rows' loads run four rows ahead (the loop is unrolled: the ring of rows is indexed
-    // statically).
+    // statically).  (Requesting the first four rows before the window is staged, so that their trip to memory runs under
+    // phases A and B, made the kernel 6 % SLOWER, measured A/B on one box: 4.39 against 4.14 ms.)
     {
-        constexpr int AHEAD = MAXN > 6 ? 2 : 4;             // (the 16-neighbour variant has no registers for more)
+        constexpr int AHEAD = SCAN_AHEAD<MAXN>::value;
         uint32_t ring[AHEAD][MAXN];
 #pragma unroll
         for (int r = 0; r < AHEAD; ++r) load_row(y0 + RG * rg + r, gx, ring[r]);
@@ -561,6 +564,14 @@ __global__ __launch_bounds__(256) void detect_kernel(DetectArgs a)
     const uint8_t *frame = a.frames + (size_t)fi * H * W;
     const bool aligned = (W & 3) == 0;
 
+    const int lo = max(0, fi - a.radius), hi = min(a.n, fi + a.radius + 1);
+    const int nn = hi - lo - 1;                              // neighbours (centre excluded)
+    const int cpos = fi - lo;                                // centre's slot in the window
+    const bool full = nn == MAXN;                            // workgroup-uniform
+    // FAST: every 4-pixel group of the tile lies inside the image and is dword-aligned (rows below the image are
+    // computed from the last row and dropped), nothing but the two planes leaves the kernel
+    const bool fast = aligned && x0 + TW <= W && a.bg_out == nullptr;
+
     // ---- phase A: stage the reflected window, columns x0-16 .. x0+143 ------------------------
     const bool interior = x0 - 16 >= 0 && x0 + TW + 16 <= W && y0 - AX >= 0 && y0 - AX + WIN_H <= H;
     if (interior && (W & 15) == 0 && (reinterpret_cast<uintptr_t>(a.frames) & 15) == 0) {
@@ -628,13 +639,6 @@ __global__ __launch_bounds__(256) void detect_kernel(DetectArgs a)
 
     // ---- phase C: per-pixel tests; a thread owns columns 4*cg .. 4*cg+3 of rows 8*rg .. 8*rg+7 and slides the
     // vertical 30-sum of its columns down those rows in registers ---------------------------------------------
-    const int lo = max(0, fi - a.radius), hi = min(a.n, fi + a.radius + 1);
-    const int nn = hi - lo - 1;                              // neighbours (centre excluded)
-    const int cpos = fi - lo;                                // centre's slot in the window
-    const bool full = nn == MAXN;                            // workgroup-uniform
-    // FAST: every 4-pixel group of the tile lies inside the image and is dword-aligned (rows below the image are
-    // computed from the last row and dropped), nothing but the two planes leaves the kernel
-    const bool fast = aligned && x0 + TW <= W && a.bg_out == nullptr;
     unsigned int c_lt = 0, c_gt = 0;
     if (full && fast) pixel_rows<MAXN, true, true>(a, s_win, s_hs, s_nib, s_rcp, s_rcpf, &s_nwork, s_work, x0, y0, fi, lo, nn, cpos, c_lt, c_gt);
     else if (full) pixel_rows<MAXN, true, false>(a, s_win, s_hs, s_nib, s_rcp, s_rcpf, &s_nwork, s_work, x0, y0, fi, lo, nn, cpos, c_lt, c_gt);

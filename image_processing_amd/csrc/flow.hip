@@ -1177,9 +1177,11 @@ int run_pairs(ipx_ctx *ctx, const uint8_t *frames, const uint8_t *extra, int fir
 int pair_batch(int H, int W, int want)
 {
     const size_t per_pair = (size_t)H * W * (6 + 4) * sizeof(float);
-    size_t b = ((size_t)48 << 30) / per_pair;            // 288 GB of HBM: 48 GB of scratch buys 512-pair batches at 1080p, 144 at 4K
+    static const long env_pairs = getenv("IPX_FLOW_BATCH_PAIRS") ? atol(getenv("IPX_FLOW_BATCH_PAIRS")) : 0;   // (A/B runs)
+    const size_t cap_pairs = env_pairs > 0 ? (size_t)env_pairs : 512, cap_bytes = env_pairs > 0 ? ((size_t)200 << 30) : ((size_t)48 << 30);
+    size_t b = cap_bytes / per_pair;                     // 288 GB of HBM: 48 GB of scratch buys 512-pair batches at 1080p, 144 at 4K
     if (b < 1) b = 1;
-    if (b > 512) b = 512;                                // measured at 1080p: 64 -> 256 pairs per batch +3 %, 256 -> 512 +1.6 %, 1024 +2.0 %
+    if (b > cap_pairs) b = cap_pairs;                    // measured at 1080p: 64 -> 256 pairs per batch +3 %, 256 -> 512 +1.6 %, 1024 +2.0 %
     if (b > (size_t)want) b = want;
     return (int)b;
 }
