@@ -5,10 +5,10 @@
 //   get_damaged_pixel_mask               ip.py:635-648  (f32 threshold chain A.2, 30x30 box mean A.3)
 //   (background > brightness_threshold)  ip.py:743      (input of remove_bright_regions)
 //
-// One 256-thread workgroup owns a 128 x 64 pixel tile of one frame (128 pixels = one 128-byte line per row of
-// every temporal neighbour).  The 30x30 window sum is an exact integer: the (128+29) x (64+29) window is staged
+// One 256-thread workgroup owns a 128 x 32 pixel tile of one frame (128 pixels = one 128-byte line per row of
+// every temporal neighbour).  The 30x30 window sum is an exact integer: the (128+29) x (32+29) window is staged
 // in LDS, summed horizontally (u16) into LDS, and every thread slides the vertical sum down its own 4 columns
-// x 8 rows in registers.  `frame > S*(1/900.0)` in double is equivalent to `900*frame > S` in integers
+// x 4 rows in registers.  `frame > S*(1/900.0)` in double is equivalent to `900*frame > S` in integers
 // (S*(1/900.0) == v exactly when S == 900 v, and the next integers are 1/900 away).  Mask bits leave the kernel
 // as 64-bit words assembled from per-thread nibbles.
 //
@@ -25,12 +25,19 @@
 
 namespace {
 
-constexpr int TW = 128, TH = 64, KS = 30, AX = 15;
-constexpr int WIN_H = TH + KS - 1;       // 93 rows
+// Tile height 32 (round 3; 64 before): 29.5 KB of LDS and 85 VGPRs per workgroup put five workgroups on a CU instead of three,
+// which the scan (short, latency-bound) needs more than it minds the taller halo: 3.91 against 4.21 ms per 1000 frames of 1080p,
+// an all-bright scene 6.97 against 7.90 ms (A/B on one box, -DIPX_DETECT_TH=64 builds the other).
+#ifndef IPX_DETECT_TH
+#define IPX_DETECT_TH 32
+#endif
+constexpr int TW = 128, TH = IPX_DETECT_TH, KS = 30, AX = 15;
+static_assert(TH == 64 || TH == 32, "tile height: 256 threads own 4 columns x TH/8 rows each");
+constexpr int WIN_H = TH + KS - 1;       // 61 rows
 constexpr int WIN_W = TW + 32;           // staged columns x0-16 .. x0+143 (16-byte aligned on both sides)
 constexpr int WIN_STRIDE = WIN_W + 16;   // bytes per staged row (176: 16-byte aligned, 44 dwords: rows 12 banks apart)
 constexpr int HS_STRIDE = TW;            // u16 per row of horizontal sums
-constexpr int RG = 8;                    // rows per thread in the per-pixel phase (4 columns x 8 rows)
+constexpr int RG = TH / 8;               // rows per thread in the per-pixel phase (4 columns x 8 rows at TH = 64)
 
 __device__ __forceinline__ int reflect101(int p, int len)
 {
@@ -324,9 +331,9 @@ __device__ __forceinline__ uint32_t pretest_four(const PreTest &t, uint32_t cen,
 // the list's entries one each -- dense lanes for the expensive code instead of a wave that runs it for 64 lanes because
 // one of them needs it.  A tile whose list overflows (bright background) runs the cut for all of its groups in the
 // per-row loop instead, as tiles without the pre-test do: the dense case, which then costs the scan on top (+15 %).
-constexpr int WORK_CAP = 512;                // groups of four pixels per tile that can wait in the list (of 2048)
+constexpr int WORK_CAP = 512;                // groups of four pixels per tile that can wait in the list (of 1024)
 // rows of neighbour dwords the scan keeps in flight (the 16-neighbour variant has registers for one)
-template <int MAXN> struct SCAN_AHEAD { static constexpr int value = MAXN > 6 ? 1 : 4; };
+template <int MAXN> struct SCAN_AHEAD { static constexpr int value = MAXN > 6 ? 1 : (RG < 4 ? RG : 4); };
 
 template <int MAXN, bool FULL, bool FAST>
 __device__ __forceinline__ void pixel_rows(const DetectArgs &a, const uint8_t *s_win, const uint16_t *s_hs,
@@ -384,42 +391,32 @@ __device__ __forceinline__ void pixel_rows(const DetectArgs &a, const uint8_t *s
             }
         }
     };
-    // the outlier cut and the two tests for the four pixels of `cen` (neighbour dwords v, window sums ws) -> two nibbles
+    // the outlier cut and the two tests for the four pixels of `cen` (neighbour dwords v, window sums ws) -> two nibbles.
+    // One pixel per trip of a rolled loop: the cut runs for listed groups and dense tiles only (see above), and rolled it
+    // holds one pixel's neighbours, sums and decisions in registers instead of four -- which is what lets five waves per
+    // SIMD run the scan.
     auto cut_four = [&](const uint32_t (&v)[MAXN], uint32_t cen, const int (&ws)[4], int gy, int x, uint32_t &dm, uint32_t &bm,
-                        unsigned &lt, unsigned &gt) {
-        BgSums sm[4];
-        bool any_hard = !bc.unit_coeff;
-#pragma unroll
+                        unsigned &lt, unsigned &gt) __attribute__((always_inline)) {   // (called by reference to register arrays)
+        int w0 = ws[0], w1 = ws[1], w2 = ws[2], w3 = ws[3];     // handed down one place per trip: no indexed register array
+#pragma unroll 1
         for (int j = 0; j < 4; ++j) {
-            sm[j] = background_sums<MAXN, FULL>(v, j, bc);
-            any_hard |= sm[j].hard;
-        }
-        float bgv[4];
+            if (!(FAST || x + j < W)) break;
+            const BgSums sm = background_sums<MAXN, FULL>(v, j, bc);
+            float bg = div_small((float)sm.Si, (float)sm.c, s_rcpf[sm.c]);   // c >= 1
+            if (__builtin_expect(sm.hard || !bc.unit_coeff, 0)) {
+                NeighbourRow<MAXN> row;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) bgv[j] = div_small((float)sm[j].Si, (float)sm[j].c, s_rcpf[sm[j].c]);   // c >= 1
-        if (__builtin_expect(any_hard, 0)) {
-            NeighbourRow<MAXN> row;
-#pragma unroll
-            for (int s = 0; s < MAXN; ++s) row.v[s] = v[s];
-            for (int j = 0; j < 4; ++j)
-                if (sm[j].hard || !bc.unit_coeff) {
-                    const float h = background_hard<MAXN>(row, j, FULL ? MAXN : nn, a.coeff, s_rcp);
-                    bgv[0] = j == 0 ? h : bgv[0]; bgv[1] = j == 1 ? h : bgv[1];
-                    bgv[2] = j == 2 ? h : bgv[2]; bgv[3] = j == 3 ? h : bgv[3];
-                }
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            if (FAST || x + j < W) {
-                const int pix = (int)__builtin_amdgcn_ubfe(cen, 8 * j, 8);
-                const float bg = bgv[j];
-                if (!FAST && a.bg_out) a.bg_out[(size_t)gy * W + x + j] = bg;
-                const float thr = damage_threshold_f32(bg);
-                const bool dmg = ((float)pix > thr) && (900 * pix > ws[j]);
-                dm |= (uint32_t)dmg << j;
-                bm |= (uint32_t)(bg > a.bg_gt) << j;
-                if (!FAST) { lt += pix < a.est_lt; gt += pix > a.frame_gt; }
+                for (int s = 0; s < MAXN; ++s) row.v[s] = v[s];
+                bg = background_hard<MAXN>(row, j, FULL ? MAXN : nn, a.coeff, s_rcp);
             }
+            const int pix = (int)__builtin_amdgcn_ubfe(cen, 8 * j, 8);
+            if (!FAST && a.bg_out) a.bg_out[(size_t)gy * W + x + j] = bg;
+            const float thr = damage_threshold_f32(bg);
+            const bool dmg = ((float)pix > thr) && (900 * pix > w0);
+            w0 = w1; w1 = w2; w2 = w3;
+            dm |= (uint32_t)dmg << j;
+            bm |= (uint32_t)(bg > a.bg_gt) << j;
+            if (!FAST) { lt += pix < a.est_lt; gt += pix > a.frame_gt; }
         }
     };
     // the per-row loop that runs the cut for every group (tiles without the pre-test, and tiles whose list overflowed)
@@ -461,7 +458,7 @@ __device__ __forceinline__ void pixel_rows(const DetectArgs &a, const uint8_t *s
         dense_rows();
         return;
     }
-    // ---- the scan: pre-test of the thread's 8 groups, the frame's pixel counters, zero nibbles.  Nothing in it is long
+    // ---- the scan: pre-test of the thread's groups (one per row it owns), the frame's pixel counters, zero nibbles.  Nothing in it is long
     // enough to hide a load, so the rows' loads run four rows ahead (the loop is unrolled: the ring of rows is indexed
     // statically).  (Requesting the first four rows before the window is staged, so that their trip to memory runs under
     // phases A and B, made the kernel 6 % SLOWER, measured A/B on one box: 4.39 against 4.14 ms.)
@@ -655,8 +652,8 @@ __global__ __launch_bounds__(256) void detect_kernel(DetectArgs a)
     __syncthreads();
 
     // ---- phase D: 16 nibbles -> one 64-bit word; thread = (plane, row, word of the tile) -------------------
-    {
-        const int plane = tid >> 7, ty = (tid >> 1) & (TH - 1), half = tid & 1;
+    if (tid < 4 * TH) {
+        const int plane = tid / (2 * TH), ty = (tid >> 1) & (TH - 1), half = tid & 1;
         const uint4 q = *reinterpret_cast<const uint4 *>(&s_nib[plane][ty][16 * half]);
         const uint64_t word = (uint64_t)(nibbles4(q.x) | (nibbles4(q.y) << 16)) |
                               ((uint64_t)(nibbles4(q.z) | (nibbles4(q.w) << 16)) << 32);

@@ -360,3 +360,45 @@ def test_unpack_dib_equals_the_avi_reader(eng, shape, tmp_path):
             assert np.array_equal(got, exp)
     finally:
         r.close()
+
+
+@pytest.mark.parametrize("radius", [1, 3, 6])
+def test_raw_planes_pretest_list_and_dense_tiles(eng, S, radius):
+    """detect_kernel's round-3 structure on its aligned tiles: the min / max row pre-test, the work list of the groups that
+    pass it, and the per-row loop for tiles whose list overflows -- on content that takes each path (dark noise with hot
+    pixels: short lists; all-bright noise: every group flagged, the dense loop; half and half; 0 / 255 mixtures: ties and
+    flags everywhere; flat frames: nothing flagged), at several brightness thresholds (fractional, 0, at and beyond 255,
+    negative = pre-test off), window radii 1, 3 and 6 (the 16-neighbour kernel) and with discarded frames."""
+    import torch
+    rng = np.random.default_rng(900 + radius)
+    n = 2 * radius + 5
+    for (h, w) in ((70, 256), (97, 388), (40, 132)):
+        kinds = []
+        dark = np.clip(rng.normal(70, 3, (n, h, w)), 0, 255)
+        hot = rng.random((n, h, w)) < 0.002
+        dark[hot] = rng.integers(150, 256, int(hot.sum()))
+        kinds.append(np.rint(dark).astype(np.uint8))
+        kinds.append(rng.integers(175, 256, (n, h, w)).astype(np.uint8))
+        half = kinds[0].copy()
+        half[:, :, w // 2:] = kinds[1][:, :, w // 2:]
+        kinds.append(half)
+        kinds.append(rng.choice(np.array([0, 255], np.uint8), size=(n, h, w)))
+        kinds.append(np.full((n, h, w), 90, np.uint8))
+        for k, frames in enumerate(kinds):
+            for thr in ((170, 100.5, 254) if k != 1 else (170, 0, 255, 300.0, -5.0)):
+                keep = (rng.random(n) < 0.8).astype(np.uint8)
+                keep[0] = 1
+                eng.set_params(dict(sliding_window_radius=radius, brightness_threshold=thr))
+                raw, bright, dense = eng.detect_raw(eng.to_device(frames), keep=torch.from_numpy(keep).to(eng.device))
+                raw = _bits_to_bool(eng, raw, h, w)
+                bright = _bits_to_bool(eng, bright, h, w)
+                dense = dense.cpu().numpy()
+                for i in range(n):
+                    if not keep[i]:
+                        assert not raw[i].any() and not bright[i].any()
+                        continue
+                    bg = S.compute_background(frames, i, radius)
+                    assert np.array_equal(raw[i], S.raw_damaged_mask(frames[i], bg)), (h, w, k, thr, i, "raw")
+                    assert np.array_equal(bright[i], bg > np.float32(thr)), (h, w, k, thr, i, "bright")
+                    assert dense[i, 0] == (frames[i] < 170).sum() and dense[i, 1] == (frames[i] > thr).sum(), (h, w, k, thr, i)
+    eng.set_params(None)
