@@ -872,12 +872,16 @@ def _load_chunk_raw_avi(video_filename, start, end, ring, device=None):
                              reader.bottom_up)
         with ThreadPoolExecutor(max_workers=_DECODE_THREADS) as pool:
             reads = [pool.submit(reader.read_region_into, off0 + a, view[a:b], 1) for a, b in spans]
-            with torch.cuda.stream(copy_stream):
-                for (a, b), done in zip(spans, reads):
-                    done.result()
-                    staged[a:b].copy_(host[a:b], non_blocking=True)
-                uploaded = torch.cuda.Event()
-                uploaded.record(copy_stream)
+            try:
+                with torch.cuda.stream(copy_stream):
+                    for (a, b), done in zip(spans, reads):
+                        done.result()
+                        staged[a:b].copy_(host[a:b], non_blocking=True)
+                    uploaded = torch.cuda.Event()
+                    uploaded.record(copy_stream)
+            except BaseException:
+                copy_stream.synchronize()                 # a failed read: no copy may still be reading the buffer
+                raise                                     # when the ring hands it to the next driver
         slot["busy"] = uploaded                           # the ring hands this buffer out again only after the copies
         return _RawChunk(slot, nbytes, end - start, rec, reader.height, reader.width, reader.bpp, reader.stride,
                          reader.bottom_up, staged, uploaded)

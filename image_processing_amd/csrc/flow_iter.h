@@ -53,6 +53,7 @@ struct FiArgs {
     float2 *flow_out;
     double *partial;            // REDUCE: [np][strips * nseg]
     int h, w, seg_rows, strips, nseg, np, ppx;
+    int sgroup;                         // strips of a pair that are resident together (workgroup order; 1 = one strip of ppx pairs)
     int sh, sw;
     const int *x_ofs, *y_ofs;
     const float *x_a, *y_b;

@@ -230,11 +230,21 @@ __global__ __launch_bounds__(FI_THREADS, 4) void flow_iter_kernel(const FiArgs a
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     if (a.prio == 1 || (a.prio == 2 && wave < 4) || (a.prio == 3 && wave >= 4)) __builtin_amdgcn_s_setprio(3);
     // Workgroups go round-robin over the 8 XCDs (id % 8) and every XCD has its own L2.  XCD x gets the
-    // pairs [x*ppx, (x+1)*ppx), and its resident workgroups are the same strip/segment of consecutive
-    // pairs, then the neighbouring strips: the expansion of frame p+1 (sampled by pair p, read in place by
-    // pair p+1) and the column halo shared by two strips are then fetched once per L2 instead of twice.
+    // pairs [x*ppx, (x+1)*ppx), and its resident workgroups (64: two per CU) are the same few strips of consecutive
+    // pairs: the expansion of frame p+1 (sampled by pair p, read in place by pair p+1) is then fetched once per L2
+    // instead of twice, and so are the 14 halo columns and the cache lines that two neighbouring strips share
+    // (a strip starts at column 114 s - 7: not on a line boundary).
     const int xcd = blockIdx.x & 7, k = blockIdx.x >> 3;
-    const int pl = k % ppx, t = k / ppx;
+    int pl = k % ppx, t = k / ppx;
+    if (a.sgroup > 1) {
+        // sgroup neighbouring strips of ppx / sgroup consecutive pairs resident together instead of one strip of ppx pairs:
+        // the 14 halo columns between two strips of a group are L2 hits too, for an expansion more at the group's ends
+        const int per_seg = ppx * strips, seg = k / per_seg, ks = k - seg * per_seg;
+        const int gi = ks / (a.sgroup * ppx), rem = ks - gi * a.sgroup * ppx;
+        const int gs = min(a.sgroup, strips - gi * a.sgroup);
+        pl = rem / gs;
+        t = seg * strips + gi * a.sgroup + (rem - pl * gs);
+    }
     const int x0 = (t % strips) * FI_TW;
     const int ys = (t / strips) * seg_rows;
     const size_t p = (size_t)xcd * ppx + pl;

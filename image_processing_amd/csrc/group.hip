@@ -481,7 +481,9 @@ extern "C" int ipx_group_submit(ipx_group *g, const uint8_t *frames_host, int n,
     IPX_REQUIRE(n / g->nd + 1 + 2 * (g->p.sliding_window_radius > 1 ? g->p.sliding_window_radius : 1) <= 65535, "at most 65535 frames (halo included) per rank");
     IPX_REQUIRE(g->p.sliding_window_radius >= 1, "sliding_window_radius must be >= 1");
     IPX_REQUIRE(g->inflight.size() < 2, "two chunks are in flight already: ipx_group_wait first");
-    if (g->broken) {
+    bool broken;
+    { std::lock_guard<std::mutex> lk(g->m); broken = g->broken; }     // (written by the ranks' threads)
+    if (broken) {
         ipx_set_error("ipx_group_submit: an earlier chunk abandoned an RCCL collective; the group cannot be used any more");
         return IPX_ERR_HIP;
     }
