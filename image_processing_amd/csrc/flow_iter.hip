@@ -294,7 +294,11 @@ __global__ __launch_bounds__(FI_THREADS, 4) void flow_iter_kernel(const FiArgs a
         FiVec v;
         if (IN == 0) {
             typedef float fi_f2 __attribute__((ext_vector_type(2)));
+#ifdef IPX_FI_FLOW_TEMPORAL   // (A/B build)
+            const fi_f2 lv = *reinterpret_cast<const fi_f2 *>(fin + (size_t)t.row * w + ax);
+#else
             const fi_f2 lv = __builtin_nontemporal_load(reinterpret_cast<const fi_f2 *>(fin + (size_t)t.row * w + ax));
+#endif
             v.p00 = make_float2(lv.x, lv.y);
         } else if (IN == 2) {
             const float2 *S0 = fin + (size_t)t.o0 * a.sw, *S1 = fin + (size_t)t.o1 * a.sw;
@@ -641,7 +645,11 @@ __global__ __launch_bounds__(FI_THREADS, 4) void flow_iter_kernel(const FiArgs a
                             // expansions, each of which a second pair reads: -1 % on the kernel, measured A/B)
                             typedef float fi_f4 __attribute__((ext_vector_type(4)));
                             const fi_f4 ov = {o[0].x, o[0].y, o[1].x, o[1].y};
+#ifdef IPX_FI_STORE_TEMPORAL   // (A/B build)
+                            *reinterpret_cast<fi_f4 *>(dst) = ov;
+#else
                             __builtin_nontemporal_store(ov, reinterpret_cast<fi_f4 *>(dst));
+#endif
                         }
                     } else {
                         if (x < w) dst[0] = o[0];
