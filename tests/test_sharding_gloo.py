@@ -1,4 +1,4 @@
-"""Frame-range sharding (image_processing_amd/sharding.py) over gloo, world sizes 2 and 3, on the CPU:
+"""Frame-range sharding (image_processing_amd/sharding.py) over gloo, world sizes 2, 3 and 8, on the CPU:
 the sharded result must equal the single-process pipeline bit for bit, including persistence runs
 and static-map sums that straddle shard boundaries.  The compute stages are the oracle's
 (tests/oracle_engine.py); what is under test is the host logic and the exchanges."""
@@ -60,6 +60,7 @@ def _worker(rank, world, port, seed, n, h, w, params, q):
     (2, 13, dict(consecutive_threshold=3, sliding_window_radius=2, static_threshold=20)),
     (3, 12, dict(consecutive_threshold=4, sliding_window_radius=4)),
     (2, 12, dict(consecutive_threshold=1)),
+    (8, 41, dict(consecutive_threshold=3, sliding_window_radius=2)),     # the node's eight ranks, uneven ranges of 5 and 6 frames
 ])
 def test_sharded_equals_single_process(world, n, params):
     from oracle import pipeline
