@@ -213,6 +213,7 @@ __device__ __forceinline__ void fi_barrier()
 // Debug build only (python -m image_processing_amd.build --stamps): shader-clock totals per wave and phase
 // of every 64th workgroup, read back with ipx_debug_fi_stamps().
 __device__ unsigned long long fi_stamps[8][8];
+__device__ unsigned long long fi_wg_times[2][16384];     // start / end (s_memtime) of every workgroup of the last level-0 launch
 #define FI_STAMP(k) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); st_acc[k] += t_ - st_t; st_t = t_; } while (0)
 #else
 #define FI_STAMP(k) do { } while (0)
@@ -447,6 +448,7 @@ __global__ __launch_bounds__(FI_THREADS, 4) void flow_iter_kernel(const FiArgs a
 
 #ifdef IPX_FI_STAMPS
     unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_t = __builtin_amdgcn_s_memtime();
+    if (tid == 0 && h > 600 && blockIdx.x < 16384) fi_wg_times[0][blockIdx.x] = st_t;
 #endif
     if (producer) {
         // Software pipeline over matrix rows: while one of the thread's two rows is finished and stored, the
@@ -663,6 +665,7 @@ __global__ __launch_bounds__(FI_THREADS, 4) void flow_iter_kernel(const FiArgs a
         }
     }
 #ifdef IPX_FI_STAMPS
+    if (tid == 0 && h > 600 && blockIdx.x < 16384) fi_wg_times[1][blockIdx.x] = __builtin_amdgcn_s_memtime();
     if ((tid & 63) == 0 && (blockIdx.x & 63) == 0 && h > 600) {
         for (int i = 0; i < 8; ++i) atomicAdd(&fi_stamps[wave][i], st_acc[i]);
         atomicAdd(&fi_stamps[wave][7], (unsigned long long)((ye - ys + FI_G - 1) / FI_G));
@@ -698,6 +701,13 @@ hipError_t ipx_flow_iter_prepare()
 }
 
 #ifdef IPX_FI_STAMPS
+extern "C" __attribute__((visibility("default"))) int ipx_debug_fi_wg_times(unsigned long long *out, int n)
+{
+    if (n > 16384) n = 16384;
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(fi_wg_times), sizeof(unsigned long long) * n, 0) != hipSuccess) return -1;
+    if (hipMemcpyFromSymbol(out + n, HIP_SYMBOL(fi_wg_times), sizeof(unsigned long long) * n, sizeof(unsigned long long) * 16384) != hipSuccess) return -1;
+    return 0;
+}
 extern "C" __attribute__((visibility("default"))) int ipx_debug_fi_stamps(unsigned long long *out64, int reset)
 {
     if (hipMemcpyFromSymbol(out64, HIP_SYMBOL(fi_stamps), sizeof(unsigned long long) * 64) != hipSuccess) return -1;
