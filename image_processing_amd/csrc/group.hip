@@ -329,11 +329,14 @@ void rank_body(Call &c, int r)
     RK_TRY(ipx_finalize(ctx, own, raw, pers_use, (const uint64_t *)stat, d_keep, nown, H, W, (uint64_t *)fin, fin3));
     RK_TRY(ipx_cluster_stats(ctx, own, (const uint64_t *)fin, d_keep, nown, H, W, d_tab, c.tdim, d_cluster, nullptr));
     RK_TRY(ipx_merge_counts(ctx, fin3, dense2, nown, d_counts5));
+    // The copy-back is enqueued only when the kernels are through: a device-to-host copy that waits in a DMA queue for the
+    // chunk's kernels holds up the NEXT chunk's upload (ipx_group_submit, side stream) queued on the same engine behind it.
+    RK_TRY(ipx_synchronize(ctx));                          // also reports a failure inside the flow stage's kernels
     RK_HIP(hipMemcpyAsync(c.flows + a, d_flows, sizeof(float) * (size_t)nown, hipMemcpyDeviceToHost, st));
     RK_HIP(hipMemcpyAsync(c.keep + a, d_keep, (size_t)nown, hipMemcpyDeviceToHost, st));
     RK_HIP(hipMemcpyAsync(c.counts + 5 * (size_t)a, d_counts5, sizeof(int64_t) * 5 * (size_t)nown, hipMemcpyDeviceToHost, st));
     RK_HIP(hipMemcpyAsync(c.cluster + 3 * (size_t)a, d_cluster, sizeof(int64_t) * 3 * (size_t)nown, hipMemcpyDeviceToHost, st));
-    RK_TRY(ipx_synchronize(ctx));                          // also reports a failure inside the flow stage's kernels
+    RK_HIP(hipStreamSynchronize(st));
     (void)g->barrier.wait(c.failed);                       // nobody reuses a buffer a neighbour may still be reading
 }
 

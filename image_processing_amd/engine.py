@@ -445,29 +445,39 @@ def _check_flows(flows):
 
 
 class _PendingChunk:
+    """The chunk's kernels are enqueued by the constructor; ``result()`` waits for them and fetches the per-frame integers.
+    The copy-back is enqueued only THEN, not behind the kernels at submit time: a device-to-host copy that sits in a DMA
+    queue waiting for 50 ms of kernels holds up the next chunks' UPLOADS queued on the same engine behind it (measured in
+    the chunk driver: one chunk in three started 17 ms late, the copy time of its frames; tools/avi_modes.py trace)."""
+
     def __init__(self, eng, frames):
         n, H, W = frames.shape
         self.n_pixels = H * W
         self.dev = eng.detect_chunk_device(frames)
         self.frames = frames                               # keep inputs and outputs alive until the copies land
-        main = torch.cuda.current_stream(eng.device)
+        self.eng = eng
         if getattr(eng, "_copy_stream", None) is None:
             eng._copy_stream = torch.cuda.Stream(eng.device)
-        done = torch.cuda.Event()
-        done.record(main)
+        self.done = torch.cuda.Event()
+        self.done.record(torch.cuda.current_stream(eng.device))
+        self.host = None
+
+    def _fetch(self):
+        self.done.synchronize()                            # (the stream goes on with the next chunk's kernels meanwhile)
         self.host = {}
-        with torch.cuda.stream(eng._copy_stream):
-            eng._copy_stream.wait_event(done)
+        with torch.cuda.stream(self.eng._copy_stream):
             for k in ("keep", "counts", "cluster", "flows"):
                 t = self.dev[k]
                 h = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
                 h.copy_(t, non_blocking=True)
                 self.host[k] = h
-            self.ready = torch.cuda.Event()
-            self.ready.record(eng._copy_stream)
+            ready = torch.cuda.Event()
+            ready.record(self.eng._copy_stream)
+        ready.synchronize()
 
     def result(self):
-        self.ready.synchronize()
+        if self.host is None:
+            self._fetch()
         keep = self.host["keep"].numpy()
         counts = self.host["counts"].numpy()
         cluster = self.host["cluster"].numpy()
@@ -475,5 +485,5 @@ class _PendingChunk:
         out = dict(total_counts=total, cluster_counts=cc, avg_sizes=cs, avg_brightnesses=cb,
                    flows=_check_flows(self.host["flows"].numpy().astype(np.float64)), keep=keep.copy(), counts=counts.copy(),
                    cluster=cluster.copy())
-        self.dev = self.frames = None
+        self.dev = self.frames = self.eng = None
         return out
