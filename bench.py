@@ -145,24 +145,31 @@ def throughput_modes(chunks_dev, H, W):
     kw = dict(plot=False, show_plots=False, save_plots=False, output_folder="results", visualise_damaged_pixels_plot=True,
               plot_damaged_pixels_plot=True, plot_heatmap_plot=True, params=None)
 
+    delivered = []
+
     def run_pinned(count):
         pending = None
         for i in range(count):
             done = ip._submit_chunk(([None] * n, pinned[i % 2]), i, kw)
             if pending is not None:
                 pending()
+                delivered.append(time.perf_counter())
             pending = done
         pending()
+        delivered.append(time.perf_counter())
     run_pinned(1)
     torch.cuda.synchronize()
     count = 4
+    del delivered[:]
     t0 = time.perf_counter()
     run_pinned(count)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     from_pinned = dict(value=round(count * n / dt, 1), unit="frames/s", chunks=count, frames_per_chunk=n,
-                       upload_gbs=round(count * n * H * W / dt / 1e9, 2),
-                       what="chunks start in pinned host memory; upload on a side stream under the previous chunk")
+                       host_to_hbm_gbs=round(count * n * H * W / dt / 1e9, 2),
+                       steady_state=round((count - 1) * n / (delivered[-1] - delivered[0]), 1),
+                       what="chunks start in pinned host memory; upload on a side stream under the previous chunk.  value = the "
+                            "whole run, whose first upload nothing overlaps; steady_state = delivery to delivery from the second chunk on")
     # (iii): an uncompressed 8-bit AVI on disk (a RIFF AVI holds 4 GB), read by image_processing.main
     nch = 4
     per = max(2, min(n, int(3.8e9 / (H * W)) // nch))
@@ -322,21 +329,29 @@ def bench_group(args):
     torch.cuda.empty_cache()
     g = Group(devices, transport=args.group_transport)
 
+    delivered = []
+
     def run(first, count):
         res, pend = [], None
         for i in range(first, first + count):
             h = g.submit(pinned[i % 2].numpy())        # the upload starts at once, under the chunk before
             if pend is not None:
                 res.append(g.wait(pend))
+                delivered.append(time.perf_counter())
             pend = h
         if pend is not None:
             res.append(g.wait(pend))
+            delivered.append(time.perf_counter())
         return res
 
     run(0, args.warmup)
+    del delivered[:]
     t0 = time.perf_counter()
     results = run(args.warmup, args.steps)
     dt = time.perf_counter() - t0
+    # (the timed steps start with an empty pipeline: the first chunk's upload is not overlapped.  Delivery to delivery
+    # is what every further chunk costs)
+    steady = (len(delivered) - 1) * n / (delivered[-1] - delivered[0]) if len(delivered) > 1 else None
     thr = float(g.params.flow_threshold)
     margins = [hostmath.flow_margin(r["flows"], thr) for r in results]
     line = dict(metric="frames/sec (whole node) at 1080p, from pinned host memory through ipx_group_*",
@@ -345,7 +360,9 @@ def bench_group(args):
                 vs_baseline=None, dtype="u8 (flow metric in f32/f64)", data="synthetic",
                 config=dict(workload="%dx%d u8, %d-frame chunks in pinned host memory, cut by frame range over %d ranks inside "
                                      "libipx (devices %s, transport %s), two chunks in flight" % (W, H, n, N, devices, g.transport),
-                            frames_per_rank=n // N, upload_gbs=round(n * H * W * args.steps / dt / 1e9, 2),
+                            frames_per_rank=n // N, host_to_hbm_gbs=round(n * H * W * args.steps / dt / 1e9, 2),
+                            steady_state=round(steady, 1) if steady else None,
+                            deliveries_ms=[round(1e3 * (t - t0), 1) for t in delivered],
                             kept_frames_last_step=int(np.sum(results[-1]["keep"])),
                             min_flow_margin=round(min(m["min_margin"] for m in margins), 6)),
                 roofline=None, cpu_baseline=None,

@@ -24,6 +24,7 @@
 // The ranks' host threads take the chunks strictly in order; ipx_group_detect_chunk = submit + wait.
 #include "ipx_internal.h"
 #include <dlfcn.h>
+#include <stdlib.h>
 #include <string.h>
 #include <atomic>
 #include <condition_variable>
@@ -102,6 +103,7 @@ struct Rank {
     hipEvent_t ev_raw = nullptr, ev_pers = nullptr, ev_maps = nullptr;
     hipEvent_t ev_up[2] = {nullptr, nullptr};   // frames of the chunk in frame buffer 0 / 1 have arrived
     uint8_t *ext[2] = {nullptr, nullptr};       // this rank's frames (+ halo) of the chunk in that buffer
+    double *tab[2] = {nullptr, nullptr};        // the caller's pow2 table, uploaded with them (behind the frames in the same slot)
     ncclComm_t comm = nullptr;
     // what the neighbours read (published before the barrier that precedes the read)
     uint64_t *raw = nullptr;       // own raw planes [nown]
@@ -211,8 +213,7 @@ void rank_body(Call &c, int r)
          *maps = nullptr, *cnt = nullptr, *edges = nullptr, *pers_all = nullptr, *maps_all = nullptr;
     RK_HIP(hipSetDevice(rk.device));
     RK_TRY(ipx_set_params(ctx, &c.p));
-    const size_t tab_bytes = sizeof(double) * (size_t)c.tdim * c.tdim;
-    const size_t misc_bytes = ipx_align_up(tab_bytes, 256) + ipx_align_up((size_t)next, 256) + ipx_align_up((size_t)nown, 256) +
+    const size_t misc_bytes = ipx_align_up((size_t)next, 256) + ipx_align_up((size_t)nown, 256) +
                               ipx_align_up(sizeof(float) * (size_t)nown, 256) + sizeof(int64_t) * 8 * (size_t)nown;
     RK_TRY(ipx_scratch(ctx, GS_MISC, misc_bytes, &misc));
     RK_TRY(ipx_scratch(ctx, WS_RAW, plane * (size_t)(nown + 2 * edge), &stack));
@@ -228,7 +229,7 @@ void rank_body(Call &c, int r)
         if (!rccl) RK_TRY(ipx_scratch(ctx, GS_MAPS_ALL, P * 8 * (size_t)nd, &maps_all));
     }
     char *mp = (char *)misc;
-    double *d_tab = (double *)mp;                    mp += ipx_align_up(tab_bytes, 256);
+    const double *d_tab = rk.tab[c.buf];                  // uploaded by ipx_group_submit with the frames
     uint8_t *keep_ext = (uint8_t *)mp;               mp += ipx_align_up((size_t)next, 256);
     uint8_t *d_keep = (uint8_t *)mp;                 mp += ipx_align_up((size_t)nown, 256);
     float *d_flows = (float *)mp;                    mp += ipx_align_up(sizeof(float) * (size_t)nown, 256);
@@ -242,8 +243,9 @@ void rank_body(Call &c, int r)
     rk.raw = raw; rk.pers = pers_own; rk.maps = maps_own;
     hipStream_t st = rk.stream;
     if (rk.status == IPX_OK && !ext_frames) { ipx_set_error("group rank %d: no frame buffer", r); rank_fail(c, rk, IPX_ERR_HIP); }
+    // (No host-to-device copy on this stream: queued behind the 36 ms uploads of two chunks on the same DMA engine, a copy of
+    // a few hundred bytes held the first chunk's kernels up for as long -- measured, bench.py --group.)
     RK_HIP(hipStreamWaitEvent(st, rk.ev_up[c.buf], 0));
-    RK_HIP(hipMemcpyAsync(d_tab, c.tab.data(), tab_bytes, hipMemcpyHostToDevice, st));
     RK_SYNC();
 
     // ---- motion test, raw planes, bright-region rejection of the owned frames ---------------------------------
@@ -506,6 +508,8 @@ extern "C" int ipx_group_submit(ipx_group *g, const uint8_t *frames_host, int n,
     int caller_device = -1;
     (void)hipGetDevice(&caller_device);
     int status = IPX_OK;
+    Call *c = new Call();
+    c->tab.assign(pow2_table_host, pow2_table_host + (size_t)tdim * tdim); c->tdim = tdim;   // (outlives its upload: freed by wait)
     for (int r = 0; r < g->nd && status == IPX_OK; ++r) {
         Rank &rk = g->ranks[r];
         int a, b;
@@ -514,10 +518,15 @@ extern "C" int ipx_group_submit(ipx_group *g, const uint8_t *frames_host, int n,
         void *ext = nullptr;
         hipError_t e = hipSetDevice(rk.device);
         if (e == hipSuccess) {
-            status = ipx_scratch(rk.ctx, buf ? GS_FRAMES_B : GS_FRAMES, (size_t)(hi - lo) * P, &ext);
+            const size_t frame_bytes = ipx_align_up((size_t)(hi - lo) * P, 256), tab_bytes = sizeof(double) * (size_t)tdim * tdim;
+            status = ipx_scratch(rk.ctx, buf ? GS_FRAMES_B : GS_FRAMES, frame_bytes + tab_bytes, &ext);
             if (status != IPX_OK) break;
             rk.ext[buf] = (uint8_t *)ext;
-            e = hipMemcpyAsync(ext, frames_host + (size_t)lo * P, (size_t)(hi - lo) * P, hipMemcpyHostToDevice, rk.up_stream);
+            rk.tab[buf] = (double *)((uint8_t *)ext + frame_bytes);
+            // the table first: the staging copy of pageable memory then does not wait for the frames ahead of it
+            e = hipMemcpyAsync(rk.tab[buf], c->tab.data(), tab_bytes, hipMemcpyHostToDevice, rk.up_stream);
+            if (e == hipSuccess)
+                e = hipMemcpyAsync(ext, frames_host + (size_t)lo * P, (size_t)(hi - lo) * P, hipMemcpyHostToDevice, rk.up_stream);
         }
         if (e == hipSuccess) e = hipEventRecord(rk.ev_up[buf], rk.up_stream);
         if (e != hipSuccess) { ipx_set_error("ipx_group_submit: upload for rank %d failed: %s", r, hipGetErrorString(e)); status = IPX_ERR_HIP; }
@@ -526,11 +535,10 @@ extern "C" int ipx_group_submit(ipx_group *g, const uint8_t *frames_host, int n,
     if (status != IPX_OK) {
         for (Rank &rk : g->ranks) { (void)hipSetDevice(rk.device); (void)hipStreamSynchronize(rk.up_stream); }
         if (caller_device >= 0) (void)hipSetDevice(caller_device);
+        delete c;
         return status;
     }
-    Call *c = new Call();
     c->g = g; c->frames = frames_host; c->n = n; c->H = H; c->W = W;
-    c->tab.assign(pow2_table_host, pow2_table_host + (size_t)tdim * tdim); c->tdim = tdim;
     c->flows = flows_host; c->keep = keep_host; c->counts = counts_host; c->cluster = cluster_host;
     c->p = g->p; c->buf = buf; c->seq = g->submitted++;
     c->ranks_left.store(g->nd);
