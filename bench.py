@@ -234,7 +234,8 @@ def bench_videos(args, world, rank, dev):
         def one_pass():
             out = []
             with contextlib.redirect_stdout(io.StringIO()):
-                for fn in files:
+                for k, fn in enumerate(files):             # (as image_processing_amd.multi's workers do)
+                    ip.queue_next_video(files[k + 1] if k + 1 < len(files) else None, S)
                     out.append(ip.main(fn, average_time=1.0, max_chunks=None, step_size=S))
             return out
 

@@ -823,6 +823,77 @@ def _ring_release(ring):
 
 
 _UPLOAD_PIECE = 64 << 20
+
+# ---- the next video's first chunk (not in the reference) ----------------------------------------------------------
+# A video's first chunk is the one decode + upload that nothing overlaps (~25 ms per GB).  A driver that processes
+# several videos one after the other (image_processing_amd/multi.py, bench.py --videos) names the next one with
+# queue_next_video(); the chunk pipeline of the CURRENT video then starts decoding it as soon as its own decode thread
+# has nothing left to read, and main(next video) finds the chunk waiting.
+_NEXT_LOCK = _threading.Lock()
+_NEXT_VIDEO = None             # (filename, step_size) announced and not started yet
+_PREFETCHED = {}               # real path -> dict(span, device, ring, future)
+_PREFETCH_POOL = None
+_PREFETCH_STATS = dict(started=0, taken=0)
+
+
+def queue_next_video(video_filename, step_size=1000):
+    """Announce the video that main() will be called on after the one it is called on next (same thread, same device,
+    this ``step_size``), so that its first chunk is decoded and uploaded under the last chunk of the current one.
+    Purely an optimisation: a video that was announced and never processed, or processed with other arguments, costs
+    one wasted decode.  ``None`` withdraws the announcement."""
+    global _NEXT_VIDEO
+    with _NEXT_LOCK:
+        _NEXT_VIDEO = (str(video_filename), int(step_size)) if video_filename is not None else None
+
+
+def _prefetch_start(device):
+    """Called by a chunk pipeline whose decode thread has read its last chunk: start on the announced video."""
+    global _NEXT_VIDEO, _PREFETCH_POOL
+    with _NEXT_LOCK:
+        nxt, _NEXT_VIDEO = _NEXT_VIDEO, None
+        if nxt is None:
+            return
+        if _PREFETCH_POOL is None:
+            from concurrent.futures import ThreadPoolExecutor
+            _PREFETCH_POOL = ThreadPoolExecutor(max_workers=1, thread_name_prefix="ipx-prefetch")
+    video, step_size = nxt
+    try:
+        num_frames, _ = _video_info(video)
+        span = (0, int(min(step_size, num_frames)))
+        if span[1] < 2:
+            return
+        ring = _ring_acquire()
+        fut = _PREFETCH_POOL.submit(_load_chunk, video, span[0], span[1], ring, device)
+        _PREFETCH_STATS["started"] += 1
+        with _NEXT_LOCK:
+            old = _PREFETCHED.pop(os.path.realpath(video), None)
+            _PREFETCHED[os.path.realpath(video)] = dict(span=span, device=device, ring=ring, future=fut)
+        if old is not None:
+            _prefetch_drop(old)
+    except Exception:                                   # noqa: BLE001 - an optimisation only: main() reads the file itself
+        pass
+
+
+def _prefetch_drop(entry):
+    try:
+        entry["future"].result()
+    except Exception:                                   # noqa: BLE001
+        pass
+    _ring_release(entry["ring"])
+
+
+def _prefetch_take(video_filename, span, device):
+    """(ring, future) of the chunk ``span`` of this video if it was prefetched for ``device``, else None; a prefetch of
+    the same video that does not fit is waited for and dropped."""
+    with _NEXT_LOCK:
+        entry = _PREFETCHED.pop(os.path.realpath(str(video_filename)), None)
+    if entry is None:
+        return None
+    if entry["span"] != tuple(span) or entry["device"] != device or not _pristine("load_video_frames"):
+        _prefetch_drop(entry)
+        return None
+    _PREFETCH_STATS["taken"] += 1
+    return entry["ring"], entry["future"]
 _UPLOAD_IN_DECODER = os.environ.get("IPX_UPLOAD_IN_DECODER", "1") != "0"   # (A/B switch: tools/avi_modes.py)
 
 
@@ -1037,13 +1108,14 @@ def _chunk_pipeline(video_filename, spans, order, kw, deliver, announce):
         return
     from concurrent.futures import ThreadPoolExecutor
     import time
-    ring = _ring_acquire()
     timeline = _TIMELINE
     try:
         import torch
         device = torch.cuda.current_device() if torch.cuda.is_available() else None
     except ImportError:
         device = None
+    ahead = _prefetch_take(video_filename, spans[order[0]], device)     # announced with queue_next_video()?
+    ring = ahead[0] if ahead else _ring_acquire()
 
     def finish(done, idx, t_taken):
         res = done()
@@ -1052,12 +1124,14 @@ def _chunk_pipeline(video_filename, spans, order, kw, deliver, announce):
         deliver(idx, res)
     try:
         with ThreadPoolExecutor(max_workers=1) as decoder:
-            nxt = decoder.submit(_load_chunk, video_filename, *spans[order[0]], ring, device)
+            nxt = ahead[1] if ahead else decoder.submit(_load_chunk, video_filename, *spans[order[0]], ring, device)
             pending = None                               # (completion, idx, time taken up) of the chunk on the GPU
             for k, idx in enumerate(order):
                 chunk = nxt.result()
                 if k + 1 < len(order):
                     nxt = decoder.submit(_load_chunk, video_filename, *spans[order[k + 1]], ring, device)
+                else:
+                    _prefetch_start(device)              # nothing left to read here: the next video's first chunk, if announced
                 announce(idx)
                 t_taken = time.perf_counter()
                 done = _submit_chunk(chunk, idx, kw)

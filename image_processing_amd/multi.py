@@ -132,7 +132,9 @@ def _worker(slot, device, jobs, main_kwargs, per_video_output, conn):
             raise RuntimeError("worker %d: no GPU visible" % slot)
         torch.cuda.set_device(int(device))
         import image_processing as ip
-        for index, video in jobs:
+        for j, (index, video) in enumerate(jobs):
+            # the next video's first chunk is decoded and uploaded under this one's last chunk (image_processing.queue_next_video)
+            ip.queue_next_video(jobs[j + 1][1] if j + 1 < len(jobs) else None, main_kwargs.get("step_size") or 1000)
             kw = dict(main_kwargs)
             for key in ("output_folder", "checkpoint_folder"):
                 if per_video_output and kw.get(key):

@@ -237,6 +237,37 @@ def test_main_on_avi(ip, tmp_path):
         assert _eq_nan(res[key], res3[key]), key
 
 
+def test_next_video_is_prefetched_and_changes_nothing(ip, tmp_path):
+    """queue_next_video: the first chunk of the video after this one is decoded under this one's last chunk; main() on
+    it then takes that chunk over.  Results are those of plain runs; a prefetch that does not fit is dropped."""
+    from image_processing_amd import avi, synth
+    files, plain = [], []
+    for k in range(3):
+        frames = synth.chunk_numpy(40 + k, (17, 18, 20)[k], 72, 96, motion_at=(5,), hot=8.0, stuck=2)
+        fn = str(tmp_path / ("v%d.avi" % k))
+        avi.write_avi(fn, list(frames), fps=5.0)
+        files.append(fn)
+        plain.append(ip.main(fn, average_time=1.0, max_chunks=None, step_size=6))
+    before = dict(ip._PREFETCH_STATS)
+    got = []
+    for k, fn in enumerate(files):
+        ip.queue_next_video(files[k + 1] if k + 1 < len(files) else None, 6)
+        got.append(ip.main(fn, average_time=1.0, max_chunks=None, step_size=6))
+    assert ip._PREFETCH_STATS["started"] - before["started"] == 2 and ip._PREFETCH_STATS["taken"] - before["taken"] == 2
+    for a, b in zip(plain, got):
+        for key in ("averages_counts", "averages_clusters", "averages_size", "averages_brightness", "times"):
+            assert _eq_nan(a[key], b[key]), key
+    # announced with one chunking, processed with another: the prefetched chunk is dropped, the result is the plain one
+    ip.queue_next_video(files[1], 6)
+    ip.main(files[0], average_time=1.0, max_chunks=None, step_size=6)
+    taken = ip._PREFETCH_STATS["taken"]
+    other = ip.main(files[1], average_time=1.0, max_chunks=None, step_size=9)
+    assert ip._PREFETCH_STATS["taken"] == taken and not ip._PREFETCHED
+    again = ip.main(files[1], average_time=1.0, max_chunks=None, step_size=9)
+    for key in ("averages_counts", "averages_clusters", "averages_size", "averages_brightness", "times"):
+        assert _eq_nan(other[key], again[key]), key
+
+
 def test_main_streams_chunks_like_the_sequential_driver(ip, tmp_path, monkeypatch):
     """The double-buffered driver (decode thread + asynchronous chunks) returns exactly what chunk-by-chunk
     calls of detect_damaged_pixels return, also with a partial last chunk and with a replaced stage."""
