@@ -81,6 +81,7 @@ PROTOTYPES = {
     "ipx_bgr2gray": (_i, [_ctx, _p, C.c_size_t, _p]),
     "ipx_unpack_dib": (_i, [_ctx, _p, C.c_size_t, _i, _i, _i, _i, _i, _i, _p]),
     "ipx_flow_metric": (_i, [_ctx, _p, _i, _i, _i, _p, _p, _p]),
+    "ipx_reserve_flow": (_i, [_ctx, _i, _i, _i]),
     "ipx_flow_status": (_i, [_ctx, C.POINTER(_i), _i]),
     "ipx_debug_fi_spin_limit": (_i, [_ctx, C.c_uint]),
     "ipx_farneback_pair": (_i, [_ctx, _p, _p, _i, _i, _p]),

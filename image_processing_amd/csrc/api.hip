@@ -1,5 +1,6 @@
 // api.hip -- context, error reporting, parameters, small helper kernels of libipx.so.
 #include "ipx_internal.h"
+#include <chrono>
 #include <dlfcn.h>
 #include <stdlib.h>
 #include <math.h>
@@ -124,6 +125,8 @@ int ipx_scratch(ipx_ctx *ctx, int s, size_t bytes, void **out)
 {
     if (bytes == 0) bytes = 256;
     if (bytes > ctx->slot_bytes[s]) {
+        static const bool trace = getenv("IPX_SCRATCH_TRACE") != nullptr;      // (debug aid: what a first call waits for)
+        const auto t0 = std::chrono::steady_clock::now();
         // growing: everything enqueued so far may still use the old arena
         IPX_CHECK_HIP(hipStreamSynchronize(ctx->stream));
         if (ctx->slot[s]) IPX_CHECK_HIP(hipFree(ctx->slot[s]));
@@ -136,6 +139,9 @@ int ipx_scratch(ipx_ctx *ctx, int s, size_t bytes, void **out)
             return IPX_ERR_NOMEM;
         }
         ctx->slot_bytes[s] = want;
+        if (trace)
+            fprintf(stderr, "[ipx scratch] slot %d: %.1f MB in %.2f ms\n", s, want / 1048576.0,
+                    std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
     }
     *out = ctx->slot[s];
     return IPX_OK;

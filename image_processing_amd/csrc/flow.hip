@@ -1092,6 +1092,10 @@ int fi_partials(const ipx_flow_plan *pl, int np)
     return f.strips * f.nseg;
 }
 
+// scratch of a batch of np pairs: level images + expansions of np + 1 frames; two flow fields per pair
+size_t flow_pyr_bytes(int np, size_t P0) { return ((size_t)(np + 1) * P0 + 64 + (size_t)(np + 1) * r_stride(P0)) * sizeof(float) + 512; }
+size_t flow_uv_bytes(int np, size_t P0) { return 2 * (size_t)np * P0 * sizeof(float2) + 512; }
+
 // Flow of `np` pairs; pair p = launch frames (p, p+1).  Either the level-0 field (*uv_out) or, when
 // uv_out is null, `fi_partials` partial sums of its magnitudes per pair in `partial`.
 int run_pairs(ipx_ctx *ctx, const uint8_t *frames, const uint8_t *extra, int first, int np, float2 **uv_out, double *partial,
@@ -1101,8 +1105,8 @@ int run_pairs(ipx_ctx *ctx, const uint8_t *frames, const uint8_t *extra, int fir
     const int nf = np + 1;
     const size_t P0 = (size_t)pl->lv[0].lh * pl->lv[0].lw;
     void *pyr, *uv;
-    IPX_TRY(ipx_scratch(ctx, SLOT_FLOW_PYR, ((size_t)nf * P0 + 64 + (size_t)nf * r_stride(P0)) * sizeof(float) + 512, &pyr));
-    IPX_TRY(ipx_scratch(ctx, SLOT_FLOW_UV, 2 * (size_t)np * P0 * sizeof(float2) + 512, &uv));
+    IPX_TRY(ipx_scratch(ctx, SLOT_FLOW_PYR, flow_pyr_bytes(np, P0), &pyr));
+    IPX_TRY(ipx_scratch(ctx, SLOT_FLOW_UV, flow_uv_bytes(np, P0), &uv));
     // two flow buffers, every iteration reads `cur` and writes `other`; the first iteration of a level
     // reads the coarser level's result (or nothing at the coarsest level)
     float2 *cur = (float2 *)uv, *other = cur + ipx_align_up((size_t)np * P0, 32);
@@ -1236,6 +1240,23 @@ extern "C" int ipx_debug_fi_spin_limit(ipx_ctx *ctx, unsigned limit)
 {
     IPX_REQUIRE(ctx, "null pointer");
     ctx->fi_spin_limit = limit;
+    return IPX_OK;
+}
+
+// The plan (its tables are uploaded) and the two large arenas of the stage for chunks of up to n frames of H x W, made
+// now rather than by the first ipx_flow_metric call.
+extern "C" int ipx_reserve_flow(ipx_ctx *ctx, int n, int H, int W)
+{
+    IPX_REQUIRE(ctx, "null pointer");
+    IPX_REQUIRE(n > 0 && H >= 2 && W >= 2, "bad sizes (frames must be at least 2x2)");
+    IPX_TRY(ipx_ctx_enter(ctx));
+    IPX_TRY(build_plan(ctx, H, W));
+    const int B = pair_batch(H, W, n > 1 ? n - 1 : 1);
+    const LevelGeom &g0 = ctx->flow_plan->lv[0];
+    const size_t P0 = (size_t)g0.lh * g0.lw;
+    void *p;
+    IPX_TRY(ipx_scratch(ctx, SLOT_FLOW_PYR, flow_pyr_bytes(B, P0), &p));
+    IPX_TRY(ipx_scratch(ctx, SLOT_FLOW_UV, flow_uv_bytes(B, P0), &p));
     return IPX_OK;
 }
 

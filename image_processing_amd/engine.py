@@ -159,6 +159,11 @@ class Engine:
         check(lib.ipx_flow_metric(self._ctx, _ptr(frames), n, H, W, _ptr(prev_frame), _ptr(flows), _ptr(keep)))
         return flows, keep
 
+    def reserve_flow(self, n, H, W):
+        """Make the flow stage's plan and large scratch arenas for chunks of up to n frames now (ipx_reserve_flow)."""
+        self._enter()
+        check(lib.ipx_reserve_flow(self._ctx, int(n), int(H), int(W)))
+
     def farneback_pair(self, prev, nxt):
         H, W = prev.shape
         flow = torch.empty((H, W, 2), dtype=torch.float32, device=self.device)

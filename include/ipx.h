@@ -126,6 +126,11 @@ int ipx_unpack_dib(ipx_ctx *ctx, const uint8_t *raw, size_t rec_bytes, int n, in
 int ipx_flow_metric(ipx_ctx *ctx, const uint8_t *frames, int n, int H, int W,
                     const uint8_t *prev_frame, float *flows, uint8_t *keep);
 int ipx_flow_status(ipx_ctx *ctx, int *raised, int clear);     /* synchronises the stream        */
+/* No counterpart in the reference: makes the stage's plan (pyramid geometry, upsampling tables) and its two large
+ * scratch arenas (tens of GB for a 1000-frame 1080p chunk) for chunks of up to n frames of H x W NOW instead of inside
+ * the first ipx_flow_metric / ipx_detect_chunk call -- for a driver that has time to spare while its first chunk is
+ * still being read.  Changes no result. */
+int ipx_reserve_flow(ipx_ctx *ctx, int n, int H, int W);
 /* test hook: number of polls after which a wave of flow_iter_kernel gives up waiting for its
  * partner waves (default 2^27, ~10 s); 0 forces the failure path described above. */
 int ipx_debug_fi_spin_limit(ipx_ctx *ctx, unsigned limit);

@@ -350,3 +350,24 @@ def test_flow_error_word_survives_a_bigger_call(eng):
         assert not e2.flow_status() and np.isfinite(flows.cpu().numpy()).all()
     finally:
         e2.close()
+
+
+@pytest.mark.gpu
+def test_reserve_flow_changes_nothing():
+    """ipx_reserve_flow: plan and arenas ahead of the first call; a smaller and a larger reservation, then the metric."""
+    import torch
+    from image_processing_amd import synth
+    from image_processing_amd.engine import Engine
+    fr = synth.chunk_torch(11, 9, 70, 94, torch.device("cuda", 0))
+    ref, _ = Engine(0).flow_metric(fr)
+    eng = Engine(0)
+    eng.reserve_flow(4, 70, 94)
+    eng.reserve_flow(40, 70, 94)
+    got, _ = eng.flow_metric(fr)
+    assert torch.equal(ref, got)
+    eng.reserve_flow(3, 40, 52)                       # another geometry in between: the plan is rebuilt on demand
+    got2, _ = eng.flow_metric(fr)
+    assert torch.equal(ref, got2)
+    with pytest.raises(Exception):
+        eng.reserve_flow(0, 70, 94)
+

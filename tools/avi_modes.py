@@ -78,7 +78,14 @@ def main():
                 setattr(cls, name, wrapper)
             timed_method(_engine.Engine, "unpack_dib")
             timed_method(_engine.Engine, "detect_chunk_async")
-            one()
+            if "cold" in sys.argv:                       # the first pass of the process: what a one-video job sees
+                t00 = time.perf_counter()
+                whole, steady, first_ms, gaps = one()
+                print("first pass of the process: whole %.0f frames/s, first chunk after %s ms, then %s" % (whole, first_ms, gaps))
+                for name, k, a, b in sorted(ev, key=lambda e: e[2]):
+                    print("    %-7s %6d  %8.1f -> %8.1f ms (%6.1f)" % (name, k, 1e3 * (a - t00), 1e3 * (b - t00), 1e3 * (b - a)))
+            else:
+                one()
             for rnd in range(8):
                 del ev[:]
                 del gpu_ev[:]
