@@ -823,6 +823,7 @@ def _ring_release(ring):
 
 
 _UPLOAD_PIECE = 64 << 20
+_UPLOAD_IN_DECODER = os.environ.get("IPX_UPLOAD_IN_DECODER", "1") != "0"   # (A/B switch: tools/avi_modes.py)
 
 # ---- the next video's first chunk (not in the reference) ----------------------------------------------------------
 # A video's first chunk is the one decode + upload that nothing overlaps (~25 ms per GB).  A driver that processes
@@ -863,7 +864,11 @@ def _prefetch_start(device):
         if span[1] < 2:
             return
         ring = _ring_acquire()
-        fut = _PREFETCH_POOL.submit(_load_chunk, video, span[0], span[1], ring, device)
+        try:
+            fut = _PREFETCH_POOL.submit(_load_chunk, video, span[0], span[1], ring, device)
+        except BaseException:
+            _ring_release(ring)
+            raise
         _PREFETCH_STATS["started"] += 1
         with _NEXT_LOCK:
             old = _PREFETCHED.pop(os.path.realpath(video), None)
@@ -894,7 +899,6 @@ def _prefetch_take(video_filename, span, device):
         return None
     _PREFETCH_STATS["taken"] += 1
     return entry["ring"], entry["future"]
-_UPLOAD_IN_DECODER = os.environ.get("IPX_UPLOAD_IN_DECODER", "1") != "0"   # (A/B switch: tools/avi_modes.py)
 
 
 def _load_chunk_raw_avi(video_filename, start, end, ring, device=None):
