@@ -480,7 +480,7 @@ def main():
     results, dt = timed(submit)
 
     # ---- pass 2: the same steps with per-kernel events (roofline, kernel table, collective times) -----
-    prof, coll, psteps, dt_prof = {}, None, max(1, args.profile_steps), None
+    prof, prof_levels, coll, psteps, dt_prof = {}, {}, None, max(1, args.profile_steps), None
     if not args.no_profile:
         eng.profile_enable(True)
         eng.profile_reset()
@@ -493,6 +493,7 @@ def main():
         fence()
         dt_prof = time.perf_counter() - t1
         prof = eng.profile_read()
+        prof_levels = eng.profile_read_flow_levels()
         eng.profile_enable(False)
         if world > 1 and hasattr(comm, "timed"):
             calls, nbytes = comm.calls, comm.bytes
@@ -539,6 +540,14 @@ def main():
                         device_copy_gbs=round(copy_gbs, 1),
                         measured_in="a separate pass of %d steps with per-kernel HIP events (%.1f ms per step; the timed "
                                     "steps run without them)" % (psteps, 1e3 * dt_prof / psteps))
+            if dom == "flow_iter" and prof_levels:
+                # the same class by pyramid level of the launch (0 = full resolution): three launches per level and batch,
+                # credited bytes as above; the level-0 launches are most of the class's time and run at another rate
+                roof["by_level"] = [dict(level=lv, launches=d["launches"], avg_launch_us=round(1e3 * d["ms"] / d["launches"], 1),
+                                         share_of_class=round(d["ms"] / v["ms"], 4),
+                                         achieved=round(d["bytes"] / (d["ms"] * 1e-3) / 1e9, 1),
+                                         frac=round(d["bytes"] / (d["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4))
+                                    for lv, d in sorted(prof_levels.items())]
         cpu = None
         if world == 1 and args.cpu_frames > 0:
             cpu = cpu_baseline(chunks[args.warmup % 2][:args.cpu_frames].cpu().numpy())

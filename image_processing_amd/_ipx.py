@@ -75,6 +75,7 @@ PROTOTYPES = {
     "ipx_profile_kernel_classes": (_i, []),
     "ipx_profile_read": (_i, [_ctx, _i, C.POINTER(C.c_char_p), C.POINTER(C.c_uint64), C.POINTER(C.c_double),
                               C.POINTER(C.c_double)]),
+    "ipx_profile_read_flow_level": (_i, [_ctx, _i, C.POINTER(C.c_uint64), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "ipx_host_register": (_i, [_p, C.c_size_t]),
     "ipx_host_unregister": (_i, [_p]),
     "ipx_upload_frames": (_i, [_ctx, _p, C.c_size_t, _p]),

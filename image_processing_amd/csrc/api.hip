@@ -277,12 +277,14 @@ static int prof_fold(ipx_ctx *ctx)
         pr.ms[pr.recs[i].kid] += ms;
         pr.bytes[pr.recs[i].kid] += pr.recs[i].bytes;
         pr.launches[pr.recs[i].kid] += 1;
+        const int lv = pr.recs[i].level;
+        if (lv >= 0 && lv < IPX_PROF_LEVELS) { pr.lvl_ms[lv] += ms; pr.lvl_bytes[lv] += pr.recs[i].bytes; pr.lvl_launches[lv] += 1; }
     }
     pr.nrecs = 0;
     return IPX_OK;
 }
 
-void ipx_prof_begin(ipx_ctx *ctx, int kid, double bytes)
+void ipx_prof_begin(ipx_ctx *ctx, int kid, double bytes, int level)
 {
     ipx_prof &pr = ctx->prof;
     if (pr.nrecs == pr.cap) {
@@ -300,7 +302,7 @@ void ipx_prof_begin(ipx_ctx *ctx, int kid, double bytes)
         }
     }
     ipx_prof_rec &r = pr.recs[pr.nrecs];
-    r.kid = kid; r.bytes = bytes;
+    r.kid = kid; r.bytes = bytes; r.level = level;
     (void)hipEventRecord(r.e0, ctx->stream);
 }
 
@@ -327,6 +329,7 @@ extern "C" int ipx_profile_reset(ipx_ctx *ctx)
     if (int e = ipx_ctx_enter(ctx)) return e;
     if (int e = prof_fold(ctx)) return e;
     for (int k = 0; k < KID_COUNT; ++k) { ctx->prof.ms[k] = 0; ctx->prof.bytes[k] = 0; ctx->prof.launches[k] = 0; }
+    for (int k = 0; k < IPX_PROF_LEVELS; ++k) { ctx->prof.lvl_ms[k] = 0; ctx->prof.lvl_bytes[k] = 0; ctx->prof.lvl_launches[k] = 0; }
     return IPX_OK;
 }
 
@@ -342,6 +345,17 @@ extern "C" int ipx_profile_read(ipx_ctx *ctx, int kid, const char **name, uint64
     if (launches) *launches = ctx->prof.launches[kid];
     if (total_ms) *total_ms = ctx->prof.ms[kid];
     if (total_bytes) *total_bytes = ctx->prof.bytes[kid];
+    return IPX_OK;
+}
+
+extern "C" int ipx_profile_read_flow_level(ipx_ctx *ctx, int level, uint64_t *launches, double *total_ms, double *total_bytes)
+{
+    IPX_REQUIRE(ctx && level >= 0 && level < IPX_PROF_LEVELS, "bad pyramid level");
+    if (int e = ipx_ctx_enter(ctx)) return e;
+    if (int e = prof_fold(ctx)) return e;
+    if (launches) *launches = ctx->prof.lvl_launches[level];
+    if (total_ms) *total_ms = ctx->prof.lvl_ms[level];
+    if (total_bytes) *total_bytes = ctx->prof.lvl_bytes[level];
     return IPX_OK;
 }
 

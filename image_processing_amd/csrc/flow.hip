@@ -1144,7 +1144,7 @@ int run_pairs(ipx_ctx *ctx, const uint8_t *frames, const uint8_t *extra, int fir
             if (probe_alone) (void)hipStreamWaitEvent(ctx->stream, probe->join, 0);
         }
         auto fi_launch = [&](int in_mode, bool red, double abytes) {  // (the kernel lives in flow_iter.hip)
-            if (ctx->prof.on) ipx_prof_begin(ctx, KID_FLOW_ITER, abytes);
+            if (ctx->prof.on) ipx_prof_begin(ctx, KID_FLOW_ITER, abytes, k);
             ipx_flow_iter_launch(ctx->stream, in_mode, red, fgrid, a);
             if (ctx->prof.on) ipx_prof_end(ctx);
         };

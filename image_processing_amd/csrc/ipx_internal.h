@@ -34,12 +34,16 @@ enum ipx_kid {
     KID_COUNT
 };
 
-struct ipx_prof_rec { int kid; double bytes; hipEvent_t e0, e1; };
+#define IPX_PROF_LEVELS 8
+struct ipx_prof_rec { int kid, level; double bytes; hipEvent_t e0, e1; };
 struct ipx_prof {
     int on;
     ipx_prof_rec *recs; int nrecs, cap;     // pending (not yet folded) launches; events are reused
     double ms[KID_COUNT], bytes[KID_COUNT];
     unsigned long long launches[KID_COUNT];
+    // the flow_iter class once more, by pyramid level of the launch (ipx_profile_read_flow_level)
+    double lvl_ms[IPX_PROF_LEVELS], lvl_bytes[IPX_PROF_LEVELS];
+    unsigned long long lvl_launches[IPX_PROF_LEVELS];
 };
 
 struct ipx_ctx {
@@ -69,7 +73,7 @@ struct ipx_range {
     ipx_range &operator=(const ipx_range &) = delete;
 };
 
-void ipx_prof_begin(ipx_ctx *ctx, int kid, double bytes);
+void ipx_prof_begin(ipx_ctx *ctx, int kid, double bytes, int level = -1);   // level: pyramid level of a flow_iter launch
 void ipx_prof_end(ipx_ctx *ctx);
 
 // Launch `kernel` on the context's stream; `abytes` = algorithmic bytes of this launch.

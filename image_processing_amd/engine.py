@@ -134,6 +134,16 @@ class Engine:
                 out[name.value.decode()] = dict(launches=int(n.value), ms=ms.value, bytes=by.value)
         return out
 
+    def profile_read_flow_levels(self):
+        """{pyramid level: dict(launches, ms, bytes)} of the class "flow_iter" since the last reset (synchronises)."""
+        out = {}
+        for lv in range(8):
+            n, ms, by = C.c_uint64(), C.c_double(), C.c_double()
+            check(lib.ipx_profile_read_flow_level(self._ctx, lv, C.byref(n), C.byref(ms), C.byref(by)))
+            if n.value:
+                out[lv] = dict(launches=int(n.value), ms=ms.value, bytes=by.value)
+        return out
+
     # ---- stages on device tensors ------------------------------------------------------------------
     def bgr2gray(self, bgr):
         assert bgr.dtype == torch.uint8 and bgr.is_contiguous() and bgr.shape[-1] == 3

@@ -87,6 +87,9 @@ int ipx_profile_reset(ipx_ctx *ctx);
 int ipx_profile_kernel_classes(void);
 int ipx_profile_read(ipx_ctx *ctx, int kernel_class, const char **name, uint64_t *launches,
                      double *total_ms, double *total_bytes);
+/* the class "flow_iter" once more, split by the pyramid level of the launch (0 = full resolution; levels 0..7):
+ * the level-0 launches are 70 % of the class's time and run at another rate than the small levels */
+int ipx_profile_read_flow_level(ipx_ctx *ctx, int level, uint64_t *launches, double *total_ms, double *total_bytes);
 
 /* ---- a1 (input side): decoded frames in host memory -> HBM, ip.py:1208-1210 hands the chunk over -------------
  * The reference keeps a chunk in host RAM; here it has to reach HBM.  ipx_upload_frames enqueues the copy on

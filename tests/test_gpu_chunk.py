@@ -371,3 +371,28 @@ def test_reserve_flow_changes_nothing():
     with pytest.raises(Exception):
         eng.reserve_flow(0, 70, 94)
 
+
+@pytest.mark.gpu
+def test_builtin_profiler_classes_and_flow_levels():
+    """ipx_profile_*: per kernel class launches / milliseconds / credited bytes of a chunk, and the flow_iter class
+    split by pyramid level (three iterations per level and batch)."""
+    import torch
+    from image_processing_amd import synth
+    from image_processing_amd.engine import Engine
+    eng = Engine(0)
+    fr = synth.chunk_torch(12, 9, 136, 200, torch.device("cuda", 0))
+    eng.detect_chunk(fr)
+    eng.profile_enable(True)
+    eng.profile_reset()
+    eng.detect_chunk(fr)
+    prof, levels = eng.profile_read(), eng.profile_read_flow_levels()
+    eng.profile_enable(False)
+    assert {"flow_iter", "polyexp", "detect"} <= set(prof)
+    assert all(v["launches"] > 0 and v["ms"] > 0 and v["bytes"] >= 0 for v in prof.values())
+    assert sorted(levels) == [0, 1, 2] and all(d["launches"] == 3 for d in levels.values())      # 136 x 200: two coarser levels
+    assert sum(d["launches"] for d in levels.values()) == prof["flow_iter"]["launches"]
+    assert abs(sum(d["ms"] for d in levels.values()) - prof["flow_iter"]["ms"]) < 1e-6 * max(1.0, prof["flow_iter"]["ms"])
+    assert levels[0]["bytes"] > levels[1]["bytes"] > levels[2]["bytes"] > 0
+    eng.profile_reset()
+    assert eng.profile_read() == {} and eng.profile_read_flow_levels() == {}
+
