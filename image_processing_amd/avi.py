@@ -10,6 +10,8 @@ decode them with cv2.
 import mmap
 import os
 import struct
+import threading
+import zlib
 
 import numpy as np
 
@@ -70,6 +72,10 @@ def write_avi(filename, frames, fps=25.0):
     return filename
 
 
+_LAYOUTS = {}                  # (real path, size, mtime) -> parsed layout of the file (see AviReader.__init__)
+_LAYOUT_LOCK = threading.Lock()
+
+
 class AviReader:
     """Random access to the frames of an uncompressed AVI.  ``read(i)`` returns (H,W) uint8 for 8-bit
     streams and (H,W,3) BGR uint8 for 24-bit streams."""
@@ -90,9 +96,25 @@ class AviReader:
             self.width = self.height = self.bpp = 0
             self.palette = None                             # (256, 3) uint8 BGR for 8-bit streams
             self._frames = []                               # (offset, length)
-            self._walk(12, min(size, 8 + struct.unpack("<I", mm[4:8])[0]))
-            if not self.bpp:
-                raise ValueError("%s: no video stream format found" % filename)
+            # The walk over the file's chunks is a Python loop over every frame (and touches a page of the file per frame):
+            # a chunk driver that opens the file once per chunk would pay it again and again, holding the interpreter lock
+            # against the thread that enqueues the GPU work.  The parsed layout of the last few files is kept.
+            st = os.fstat(self._fh.fileno())
+            # (size + modification time + checksums of the file's head, where the stream format and palette are, and tail,
+            # where the index is: a rewritten file of the same length within the clock's granularity is still another file)
+            key = (os.path.realpath(filename), st.st_size, st.st_mtime_ns, zlib.crc32(mm[:4096]), zlib.crc32(mm[max(0, size - 4096):]))
+            with _LAYOUT_LOCK:
+                known = _LAYOUTS.get(key)
+            if known is not None:
+                self.fps, self.width, self.height, self.bpp, self.palette, self._bottom_up, self._frames = known
+            else:
+                self._walk(12, min(size, 8 + struct.unpack("<I", mm[4:8])[0]))
+                if not self.bpp:
+                    raise ValueError("%s: no video stream format found" % filename)
+                with _LAYOUT_LOCK:
+                    if len(_LAYOUTS) >= 8:
+                        _LAYOUTS.pop(next(iter(_LAYOUTS)))
+                    _LAYOUTS[key] = (self.fps, self.width, self.height, self.bpp, self.palette, self._bottom_up, self._frames)
             self._stride = (self.width * self.bpp // 8 + 3) & ~3
         except Exception:                                   # nothing stays open behind a failed open
             self.close()
